@@ -1,0 +1,123 @@
+/*
+ * ofasr.h -- C ABI of libofasr_hip.so: the MI355X (gfx950) kernels of the OFA-SR supernet hot
+ * path (DynamicMBConvLayer stack + PixelShuffle upsampler).
+ *
+ * The reference (twice154/ofa-for-super-resolution) has NO native boundary: its hot path is
+ * Python modules calling ATen.  Each entry point below replaces one ATen
+ * call site of the reference; the host-side mirror of the reference's Python operator surface
+ * (ofa-for-super-resolution_amd/elastic_nn/modules/dynamic_op.py, ...) binds these through
+ * ctypes.  INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes, no torch types; every call is asynchronous on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream).
+ *   - returns OFASR_OK (0) or a negative ofasr_status; never throws, never allocates, never
+ *     synchronises; no global mutable state except a thread-local last-error string.
+ *     Safe to call from several host threads on different streams, and inside hipGraph capture.
+ *   - activations are NCHW-contiguous, `dtype` selects their element type (f32 / f16 / bf16);
+ *     weights / filters / gradients of weights are ALWAYS fp32 (master weights), accumulation
+ *     is fp32.  16-bit activation paths round once, on store.
+ *   - weight SLICES are read in place: `ldw` is the row stride (in elements) of the max-size
+ *     parameter, so `weight[:out, :in]` (dynamic_op.py:108) costs no `.contiguous()` copy.
+ *   - workspace: caller-allocated device scratch, size from the matching *_workspace() query;
+ *     contents need not be initialised.
+ */
+#ifndef OFASR_H
+#define OFASR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFASR_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+    OFASR_OK = 0,
+    OFASR_ERR_INVALID_ARG = -1, /* null pointer, non-positive size, bad enum */
+    OFASR_ERR_UNSUPPORTED = -2, /* shape/dtype outside what the kernels implement */
+    OFASR_ERR_WORKSPACE = -3,   /* workspace missing or too small */
+    OFASR_ERR_LAUNCH = -4       /* hipLaunchKernel reported an error */
+} ofasr_status;
+
+typedef enum { OFASR_F32 = 0, OFASR_F16 = 1, OFASR_BF16 = 2 } ofasr_dtype;
+
+int ofasr_version(void);
+/* message of the last failing call made by THIS host thread ("" if none) */
+const char* ofasr_last_error_string(void);
+const char* ofasr_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * PixelShuffle / PixelUnshuffle  -- replaces nn.PixelShuffle(2) (reference ofa/utils.py:309-310,
+ * used by ConvLayer act 'pixelshuffle', ofa_mbs4.py:120) and pixel_unshuffle's one-hot strided
+ * conv (ofa/utils.py:383-397).  Pure byte permutation, bit-exact, elem_size in {1,2,4,8}.
+ *   shuffle:   x [N, C*r*r, H, W] -> y [N, C, H*r, W*r],  y[n,c,h*r+i,w*r+j] = x[n,c*r*r+i*r+j,h,w]
+ *   unshuffle: x [N, C, H*r, W*r] -> y [N, C*r*r, H, W]   (inverse map)
+ * Each is the other's gradient map.
+ * ------------------------------------------------------------------------------------------- */
+int ofasr_pixel_shuffle(const void* x, void* y, int64_t N, int64_t C, int64_t H, int64_t W,
+                        int r, int elem_size, void* stream);
+int ofasr_pixel_unshuffle(const void* x, void* y, int64_t N, int64_t C, int64_t H, int64_t W,
+                          int r, int elem_size, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Elastic-kernel filter  -- replaces DynamicSeparableConv2d.get_active_filter
+ * (reference ofa/elastic_nn/modules/dynamic_op.py:46-71 + sub_filter_start_end,
+ * ofa/imagenet_codebase/utils/__init__.py:89-94): centre crop of the max-size depthwise weight,
+ * optionally passed through the learned '%dto%d_matrix' chain (F.linear => f . M^T).
+ *   w_max  [Cmax, kmax, kmax] fp32 (rows c < C are used)
+ *   ks     HOST array ks[0] > ks[1] > ... > ks[nsteps]; ks[0] = kmax, ks[nsteps] = active K
+ *   mats   HOST array of nsteps DEVICE pointers, mats[s] = [ks[s+1]^2, ks[s+1]^2] fp32
+ *   transform 0: KERNEL_TRANSFORM_MODE None -> plain centre crop (mats may be NULL)
+ *   f      [C, K, K] fp32 (out)
+ * kmax <= 9, nsteps <= 3.
+ * bwd: df [C,K,K] -> dw_max [Cmax,kmax,kmax] rows c<C FULLY written (zeros outside the crop
+ *      window; rows >= C untouched -- caller pre-zeroes them), dmats[s] written for every
+ *      walked step (host array of device pointers; ignored when transform == 0).
+ * ------------------------------------------------------------------------------------------- */
+int ofasr_ktransform_fwd(const float* w_max, const int* ks, int nsteps, const float* const* mats,
+                         int transform, float* f, int64_t C, void* stream);
+size_t ofasr_ktransform_bwd_workspace(const int* ks, int nsteps, int64_t C);
+int ofasr_ktransform_bwd(const float* w_max, const int* ks, int nsteps, const float* const* mats,
+                         int transform, const float* df, float* dw_max, float* const* dmats,
+                         int64_t C, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Depthwise KxK convolution, stride 1, dilation 1, zero padding K/2  -- replaces the
+ * F.conv2d(groups=C) of DynamicSeparableConv2d.forward (dynamic_op.py:73-84) and its autograd.
+ *   x, y, dy, dx [N, C, H, W] (`dtype`);  f, df [C, K, K] fp32;  K in {1,3,5,7}
+ * ------------------------------------------------------------------------------------------- */
+int ofasr_dwconv_fwd(const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H,
+                     int64_t W, int K, int dtype, void* stream);
+int ofasr_dwconv_dgrad(const void* dy, const float* f, void* dx, int64_t N, int64_t C, int64_t H,
+                       int64_t W, int K, int dtype, void* stream);
+size_t ofasr_dwconv_wgrad_workspace(int64_t N, int64_t C, int64_t H, int64_t W, int K);
+int ofasr_dwconv_wgrad(const void* dy, const void* x, float* df, int64_t N, int64_t C, int64_t H,
+                       int64_t W, int K, int dtype, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pointwise (1x1) convolution on an in-place weight slice (MFMA)  -- replaces
+ * DynamicPointConv2d.forward (dynamic_op.py:104-112: weight[:out,:in].contiguous() + F.conv2d)
+ * and its autograd.
+ *   x  [N, Cin, HW]   y [N, Cout, HW]   (`dtype`)
+ *   w  fp32, element (co, ci) at w[co*ldw + ci]  (co < Cout, ci < Cin)
+ *   fwd:   y[n,co,p]  = sum_ci w[co,ci] * x[n,ci,p]
+ *   dgrad: dx[n,ci,p] = sum_co w[co,ci] * dy[n,co,p]
+ *   wgrad: dw[co*ldw+ci] = sum_{n,p} dy[n,co,p] * x[n,ci,p]   (only the slice is written)
+ * ------------------------------------------------------------------------------------------- */
+int ofasr_pwconv_fwd(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin,
+                     int64_t Cout, int64_t HW, int dtype, void* stream);
+int ofasr_pwconv_dgrad(const void* dy, const float* w, int64_t ldw, void* dx, int64_t N,
+                       int64_t Cin, int64_t Cout, int64_t HW, int dtype, void* stream);
+size_t ofasr_pwconv_wgrad_workspace(int64_t N, int64_t Cin, int64_t Cout, int64_t HW);
+int ofasr_pwconv_wgrad(const void* dy, const void* x, float* dw, int64_t ldw, int64_t N,
+                       int64_t Cin, int64_t Cout, int64_t HW, int dtype, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFASR_H */

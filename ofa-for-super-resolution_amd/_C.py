@@ -1,0 +1,84 @@
+"""ctypes binding of libofasr_hip.so (C ABI: include/ofasr.h).
+
+This is the whole FFI layer: plain pointers and sizes in, status code out.  The library is
+built in-tree by csrc/build.sh (hipcc --offload-arch=gfx950); it is NOT built lazily at import
+on a GPU box -- `__graft_entry__.build()` does it -- and a missing library is a hard error:
+there is no fallback path.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libofasr_hip.so")
+
+F32, F16, BF16 = 0, 1, 2
+
+_lib = None
+
+_c_i64 = ctypes.c_int64
+_c_int = ctypes.c_int
+_c_vp = ctypes.c_void_p
+_c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); every symbol declared in include/ofasr.h
+SIGNATURES = {
+    "ofasr_version": (_c_int, []),
+    "ofasr_last_error_string": (ctypes.c_char_p, []),
+    "ofasr_status_string": (ctypes.c_char_p, [_c_int]),
+    "ofasr_pixel_shuffle": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp]),
+    "ofasr_pixel_unshuffle": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp]),
+    "ofasr_ktransform_fwd": (_c_int, [_c_vp, ctypes.POINTER(_c_int), _c_int, ctypes.POINTER(_c_vp), _c_int,
+                                      _c_vp, _c_i64, _c_vp]),
+    "ofasr_ktransform_bwd_workspace": (_c_sz, [ctypes.POINTER(_c_int), _c_int, _c_i64]),
+    "ofasr_ktransform_bwd": (_c_int, [_c_vp, ctypes.POINTER(_c_int), _c_int, ctypes.POINTER(_c_vp), _c_int, _c_vp,
+                                      _c_vp, ctypes.POINTER(_c_vp), _c_i64, _c_vp, _c_sz, _c_vp]),
+    "ofasr_dwconv_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp]),
+    "ofasr_dwconv_dgrad": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp]),
+    "ofasr_dwconv_wgrad_workspace": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_int]),
+    "ofasr_dwconv_wgrad": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp,
+                                    _c_sz, _c_vp]),
+    "ofasr_pwconv_fwd": (_c_int, [_c_vp, _c_vp, _c_i64, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_vp]),
+    "ofasr_pwconv_dgrad": (_c_int, [_c_vp, _c_vp, _c_i64, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_vp]),
+    "ofasr_pwconv_wgrad_workspace": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64]),
+    "ofasr_pwconv_wgrad": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_vp,
+                                    _c_sz, _c_vp]),
+}
+
+
+class OfasrError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """compile csrc/*.hip -> csrc/libofasr_hip.so (gfx950)."""
+    global _lib
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["bash", os.path.join(_HERE, "csrc", "build.sh")])
+    _lib = None
+    return LIB_PATH
+
+
+def lib():
+    """the loaded library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OfasrError(
+                "HIP extension %s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for the OFA-SR hot path." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the ABI and the header drift apart
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        L = lib()
+        raise OfasrError("%s failed: %s (%s)" % (
+            what, L.ofasr_status_string(status).decode(), L.ofasr_last_error_string().decode()))

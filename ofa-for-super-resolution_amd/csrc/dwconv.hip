@@ -1,0 +1,325 @@
+// dwconv.hip -- depthwise KxK convolution (stride 1, zero pad K/2) fwd / dgrad / wgrad for gfx950.
+//
+// Replaces F.conv2d(groups=C) in DynamicSeparableConv2d.forward (reference
+// ofa/elastic_nn/modules/dynamic_op.py:73-84) and its autograd (dgrad = same conv with the
+// flipped filter, wgrad = per-channel K*K reductions over N*H*W).
+//
+// Roofline: HBM.  Algorithmic bytes per launch = B * 2 * N*C*H*W (+ 4*C*K*K), B = elem size;
+// flops 2*K*K per output, i.e. 2.25 (k3) .. 12.25 (k7) flop/B in fp32 -- left of the fp32 VALU
+// ridge (157 TF / 8 TB/s ~ 20 flop/B), but at k=7 the 49 FMAs per output leave < 2x VALU slack, so
+// the inner loop is kept to exactly K*K FMAs + (K-1) lane shifts per input row.
+//
+// Decomposition ("wave strip"): a wave owns 64 adjacent columns of one (n,c) plane -- one NCHW
+// image row per lane-row, 256 contiguous bytes per wave load in fp32 -- and walks down the rows.
+// Each input row is loaded ONCE; its K column-shifted versions come from lane shuffles (no LDS
+// tile), and it is pushed into a ring of K running output rows held in registers (static
+// indexing via unroll-by-K).  The K*K filter taps of the plane's channel are wave-uniform and
+// live in SGPRs.  For W <= 64 (the MB stack runs at LR resolution: 64x64, 48x48) the zero padding
+// falls out of the shuffles (lanes past the row edge hold 0); wider rows are cut into overlapping
+// strips of 64 input columns producing 64-2*pad outputs.
+#include "ofasr_common.h"
+
+namespace ofasr {
+
+constexpr int DW_WAVES = 4;  // waves per block
+
+// value held by lane (lane + d), 0 when that lane is outside the wave
+template <int D>
+__device__ __forceinline__ float lane_shift(float v, int lane) {
+    if (D == 0) return v;
+    const int src = lane + D;
+    const float t = __shfl(v, src & 63, 64);
+    return (src >= 0 && src < 64) ? t : 0.f;
+}
+
+template <int K>
+struct Strips {
+    static constexpr int PAD = K / 2;
+    // W <= 64: one strip, lane == column, every lane produces output.
+    // W  > 64: strips of 64 input columns starting at s*(64-2*PAD) - PAD; lanes [PAD, 64-PAD) produce output.
+    static __host__ __device__ int count(int W) { return W <= 64 ? 1 : (W + (64 - 2 * PAD) - 1) / (64 - 2 * PAD); }
+    static __device__ int col0(int W, int s) { return W <= 64 ? 0 : s * (64 - 2 * PAD) - PAD; }
+    static __device__ bool core(int W, int lane) { return W <= 64 ? true : (lane >= PAD && lane < 64 - PAD); }
+};
+
+// ------------------------------------------------------------------------------- fwd / dgrad
+// unit = (plane, strip, row chunk).  FLIP selects the 180-degree rotated filter (dgrad).
+template <typename T, int K, bool FLIP>
+__global__ void __launch_bounds__(64 * DW_WAVES) dw_strip_kernel(const T* __restrict__ x, const float* __restrict__ f,
+                                                                 T* __restrict__ y, int C, int H, int W,
+                                                                 int nstrips, int nchunks, int rows_per_chunk,
+                                                                 long long units) {
+    constexpr int PAD = K / 2;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long unit = (long long)blockIdx.x * DW_WAVES + wave;
+    if (unit >= units) return;
+    const int chunk = (int)(unit % nchunks);
+    const long long u2 = unit / nchunks;
+    const int strip = (int)(u2 % nstrips);
+    const long long plane = u2 / nstrips;
+    const int c = (int)(plane % C);
+
+    float taps[K * K];
+#pragma unroll
+    for (int e = 0; e < K * K; ++e) taps[e] = f[(long long)c * K * K + (FLIP ? (K * K - 1 - e) : e)];
+
+    const int col = Strips<K>::col0(W, strip) + lane;
+    const bool in_col = col >= 0 && col < W;
+    const bool out_col = in_col && Strips<K>::core(W, lane);
+    const int h0 = chunk * rows_per_chunk;
+    const int h1 = min(H, h0 + rows_per_chunk);
+    const T* xp = x + plane * (long long)H * W + col;
+    T* yp = y + plane * (long long)H * W + col;
+
+    float acc[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) acc[i] = 0.f;
+
+    const int hstart = h0 - PAD;
+    const int niter = (h1 - h0) + 2 * PAD;
+    for (int base = 0; base < niter; base += K) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int t = base + u;
+            const int hin = hstart + t;
+            float v = 0.f;
+            if (t < niter && hin >= 0 && hin < H && in_col) v = to_float(xp[(long long)hin * W]);
+            float s[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                switch (j - PAD) {  // compile-time after unrolling
+                    case -3: s[j] = lane_shift<-3>(v, lane); break;
+                    case -2: s[j] = lane_shift<-2>(v, lane); break;
+                    case -1: s[j] = lane_shift<-1>(v, lane); break;
+                    case 0: s[j] = v; break;
+                    case 1: s[j] = lane_shift<1>(v, lane); break;
+                    case 2: s[j] = lane_shift<2>(v, lane); break;
+                    default: s[j] = lane_shift<3>(v, lane); break;
+                }
+            }
+            // input row t feeds filter row i of the output row held in slot (u - i) mod K
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                float a = acc[(u - i + K) % K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) a = fmaf(taps[i * K + j], s[j], a);
+                acc[(u - i + K) % K] = a;
+            }
+            // the output row that just received its last (i = K-1) contribution
+            const int hout = hin - PAD;
+            if (t < niter && hout >= h0 && hout < h1 && out_col)
+                yp[(long long)hout * W] = from_float<T>(acc[(u + 1) % K]);
+            acc[(u + 1) % K] = 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------- wgrad
+// unit = (channel, part): the wave walks images n = part, part+nparts, ... of channel c, all strips,
+// all rows, keeping K*K lane-partial sums;  df_part[part][c][i][j] = sum dy[h][w-j+pad] * x[h+i-pad][w]
+template <typename T, int K>
+__global__ void __launch_bounds__(64 * DW_WAVES) dw_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                 float* __restrict__ part_out, int N, int C, int H,
+                                                                 int W, int nstrips, int nparts, long long units) {
+    constexpr int PAD = K / 2;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long unit = (long long)blockIdx.x * DW_WAVES + wave;
+    if (unit >= units) return;
+    const int part = (int)(unit % nparts);
+    const int c = (int)(unit / nparts);
+
+    float acc[K * K];
+#pragma unroll
+    for (int e = 0; e < K * K; ++e) acc[e] = 0.f;
+
+    for (int n = part; n < N; n += nparts) {
+        const long long plane = (long long)n * C + c;
+        for (int strip = 0; strip < nstrips; ++strip) {
+            const int col = Strips<K>::col0(W, strip) + lane;
+            const bool in_col = col >= 0 && col < W;
+            const bool own = in_col && Strips<K>::core(W, lane);  // this lane owns x column `col`
+            const T* dp = dy + plane * (long long)H * W + col;
+            const T* xp = x + plane * (long long)H * W + col;
+            float xr[K];  // ring of x rows: slot m mod K holds row (m - PAD)
+#pragma unroll
+            for (int m = 0; m < K - 1; ++m) {
+                const int r = m - PAD;
+                xr[m] = (own && r >= 0 && r < H) ? to_float(xp[(long long)r * W]) : 0.f;
+            }
+            xr[K - 1] = 0.f;
+            for (int base = 0; base < H; base += K) {
+#pragma unroll
+                for (int u = 0; u < K; ++u) {
+                    const int h = base + u;
+                    const int rnew = h + PAD;
+                    xr[(u + K - 1) % K] =
+                        (own && h < H && rnew < H) ? to_float(xp[(long long)rnew * W]) : 0.f;
+                    const float g = (h < H && in_col) ? to_float(dp[(long long)h * W]) : 0.f;
+                    float gs[K];  // gs[j](lane) = dy(lane - j + PAD)
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        switch (PAD - j) {
+                            case -3: gs[j] = lane_shift<-3>(g, lane); break;
+                            case -2: gs[j] = lane_shift<-2>(g, lane); break;
+                            case -1: gs[j] = lane_shift<-1>(g, lane); break;
+                            case 0: gs[j] = g; break;
+                            case 1: gs[j] = lane_shift<1>(g, lane); break;
+                            case 2: gs[j] = lane_shift<2>(g, lane); break;
+                            default: gs[j] = lane_shift<3>(g, lane); break;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < K; ++i) {
+                        const float xv = xr[(u + i) % K];  // x row h + i - PAD
+#pragma unroll
+                        for (int j = 0; j < K; ++j) acc[i * K + j] = fmaf(gs[j], xv, acc[i * K + j]);
+                    }
+                }
+            }
+        }
+    }
+    float* out = part_out + ((long long)part * C + c) * (K * K);
+#pragma unroll
+    for (int e = 0; e < K * K; ++e) {
+        const float s = wave_sum(acc[e]);
+        if (lane == 0) out[e] = s;
+    }
+}
+
+// df[c][e] = sum_part part_out[part][c][e]   (fixed order => deterministic)
+__global__ void __launch_bounds__(256) dw_wgrad_reduce_kernel(const float* __restrict__ part_out,
+                                                              float* __restrict__ df, int nparts, long long CKK) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= CKK) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part_out[(long long)p * CKK + idx];
+    df[idx] = s;
+}
+
+static int wgrad_parts(int64_t N, int64_t C) {
+    // enough waves to fill 256 CUs x ~8 waves, at most one part per image
+    int64_t want = cdiv(2048, C > 0 ? C : 1);
+    if (want < 1) want = 1;
+    if (want > N) want = N;
+    return (int)want;
+}
+
+template <typename T, bool FLIP>
+static int launch_conv(const char* name, const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H,
+                       int64_t W, int K, hipStream_t st) {
+    const int rows_per_chunk = H <= 32 ? (int)H : 32;
+    const int nchunks = (int)cdiv(H, rows_per_chunk);
+#define OFASR_DW_LAUNCH(KK)                                                                                  \
+    {                                                                                                        \
+        const int nstrips = Strips<KK>::count((int)W);                                                       \
+        const long long units = (long long)N * C * nstrips * nchunks;                                        \
+        hipLaunchKernelGGL((dw_strip_kernel<T, KK, FLIP>), dim3((unsigned)cdiv(units, DW_WAVES)),            \
+                           dim3(64 * DW_WAVES), 0, st, (const T*)x, f, (T*)y, (int)C, (int)H, (int)W, nstrips, \
+                           nchunks, rows_per_chunk, units);                                                  \
+    }
+    switch (K) {
+        case 1: OFASR_DW_LAUNCH(1); break;
+        case 3: OFASR_DW_LAUNCH(3); break;
+        case 5: OFASR_DW_LAUNCH(5); break;
+        default: OFASR_DW_LAUNCH(7); break;
+    }
+#undef OFASR_DW_LAUNCH
+    return check_launch(name);
+}
+
+static int check_conv_args(const char* name, const void* a, const void* b, const void* c, int64_t N, int64_t C,
+                           int64_t H, int64_t W, int K, int dtype) {
+    OFASR_REQUIRE(a && b && c, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(N >= 0 && C >= 0 && H >= 0 && W >= 0, OFASR_ERR_INVALID_ARG, "%s: negative size", name);
+    OFASR_REQUIRE(K == 1 || K == 3 || K == 5 || K == 7, OFASR_ERR_UNSUPPORTED, "%s: K=%d not in {1,3,5,7}", name, K);
+    OFASR_REQUIRE(dtype == OFASR_F32 || dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_INVALID_ARG,
+                  "%s: bad dtype %d", name, dtype);
+    OFASR_REQUIRE(C <= INT32_MAX && H <= INT32_MAX && W <= INT32_MAX && N <= INT32_MAX, OFASR_ERR_UNSUPPORTED,
+                  "%s: dimension too large", name);
+    return OFASR_OK;
+}
+
+template <bool FLIP>
+static int conv_entry(const char* name, const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H,
+                      int64_t W, int K, int dtype, void* stream) {
+    int rc = check_conv_args(name, x, f, y, N, C, H, W, K, dtype);
+    if (rc) return rc;
+    if (N * C * H * W == 0) return OFASR_OK;
+    hipStream_t st = as_stream(stream);
+    switch (dtype) {
+        case OFASR_F32: return launch_conv<float, FLIP>(name, x, f, y, N, C, H, W, K, st);
+        case OFASR_F16: return launch_conv<f16_t, FLIP>(name, x, f, y, N, C, H, W, K, st);
+        default: return launch_conv<bf16_t, FLIP>(name, x, f, y, N, C, H, W, K, st);
+    }
+}
+
+template <typename T>
+static int launch_wgrad(const char* name, const void* dy, const void* x, float* df, int64_t N, int64_t C,
+                        int64_t H, int64_t W, int K, float* ws, hipStream_t st) {
+    const int nparts = wgrad_parts(N, C);
+    const long long units = (long long)C * nparts;
+#define OFASR_DW_WG(KK)                                                                                        \
+    hipLaunchKernelGGL((dw_wgrad_kernel<T, KK>), dim3((unsigned)cdiv(units, DW_WAVES)), dim3(64 * DW_WAVES), 0, \
+                       st, (const T*)dy, (const T*)x, ws, (int)N, (int)C, (int)H, (int)W,                      \
+                       Strips<KK>::count((int)W), nparts, units)
+    switch (K) {
+        case 1: OFASR_DW_WG(1); break;
+        case 3: OFASR_DW_WG(3); break;
+        case 5: OFASR_DW_WG(5); break;
+        default: OFASR_DW_WG(7); break;
+    }
+#undef OFASR_DW_WG
+    int rc = check_launch(name);
+    if (rc) return rc;
+    const long long CKK = (long long)C * K * K;
+    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)cdiv(CKK, 256)), dim3(256), 0, st, ws, df, nparts,
+                       CKK);
+    return check_launch(name);
+}
+
+}  // namespace ofasr
+
+using namespace ofasr;
+
+OFASR_EXPORT int ofasr_dwconv_fwd(const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H,
+                                  int64_t W, int K, int dtype, void* stream) {
+    return conv_entry<false>("ofasr_dwconv_fwd", x, f, y, N, C, H, W, K, dtype, stream);
+}
+
+OFASR_EXPORT int ofasr_dwconv_dgrad(const void* dy, const float* f, void* dx, int64_t N, int64_t C, int64_t H,
+                                    int64_t W, int K, int dtype, void* stream) {
+    return conv_entry<true>("ofasr_dwconv_dgrad", dy, f, dx, N, C, H, W, K, dtype, stream);
+}
+
+OFASR_EXPORT size_t ofasr_dwconv_wgrad_workspace(int64_t N, int64_t C, int64_t H, int64_t W, int K) {
+    (void)H;
+    (void)W;
+    if (N <= 0 || C <= 0 || K <= 0) return 0;
+    return (size_t)wgrad_parts(N, C) * (size_t)C * (size_t)K * (size_t)K * sizeof(float);
+}
+
+OFASR_EXPORT int ofasr_dwconv_wgrad(const void* dy, const void* x, float* df, int64_t N, int64_t C, int64_t H,
+                                    int64_t W, int K, int dtype, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    const char* name = "ofasr_dwconv_wgrad";
+    int rc = check_conv_args(name, dy, x, df, N, C, H, W, K, dtype);
+    if (rc) return rc;
+    if (C == 0) return OFASR_OK;
+    hipStream_t st = as_stream(stream);
+    if (N * H * W == 0) {
+        hipError_t e = hipMemsetAsync(df, 0, (size_t)C * K * K * sizeof(float), st);
+        OFASR_REQUIRE(e == hipSuccess, OFASR_ERR_LAUNCH, "%s: memset failed", name);
+        return OFASR_OK;
+    }
+    const size_t need = ofasr_dwconv_wgrad_workspace(N, C, H, W, K);
+    OFASR_REQUIRE(workspace && workspace_bytes >= need, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B",
+                  name, workspace_bytes, need);
+    float* ws = (float*)workspace;
+    switch (dtype) {
+        case OFASR_F32: return launch_wgrad<float>(name, dy, x, df, N, C, H, W, K, ws, st);
+        case OFASR_F16: return launch_wgrad<f16_t>(name, dy, x, df, N, C, H, W, K, ws, st);
+        default: return launch_wgrad<bf16_t>(name, dy, x, df, N, C, H, W, K, ws, st);
+    }
+}

@@ -1,0 +1,88 @@
+// ofasr_common.h -- shared device/host helpers for the gfx950 kernels.  HIP only, CDNA4 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/ofasr.h"
+
+#define OFASR_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace ofasr {
+
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return OFASR_ERR_LAUNCH;
+    }
+    return OFASR_OK;
+}
+
+#define OFASR_REQUIRE(cond, code, ...)      \
+    do {                                    \
+        if (!(cond)) {                      \
+            ofasr::set_error(__VA_ARGS__);  \
+            return (code);                  \
+        }                                   \
+    } while (0)
+
+// ---- 16-bit element types carried as raw bits -------------------------------------------------
+struct bf16_t { uint16_t v; };
+struct f16_t { uint16_t v; };
+
+__device__ __forceinline__ float to_float(float x) { return x; }
+__device__ __forceinline__ float to_float(bf16_t x) { return __uint_as_float(((uint32_t)x.v) << 16); }
+__device__ __forceinline__ float to_float(f16_t x) {
+    _Float16 h;
+    __builtin_memcpy(&h, &x.v, 2);
+    return (float)h;
+}
+
+template <typename T> __device__ __forceinline__ T from_float(float x);
+template <> __device__ __forceinline__ float from_float<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_float<bf16_t>(float x) {
+    // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN) on gfx950
+    __bf16 b = (__bf16)x;
+    bf16_t r;
+    __builtin_memcpy(&r.v, &b, 2);
+    return r;
+}
+template <> __device__ __forceinline__ f16_t from_float<f16_t>(float x) {
+    _Float16 h = (_Float16)x;
+    f16_t r;
+    __builtin_memcpy(&r.v, &h, 2);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    return (uint32_t)from_float<bf16_t>(lo).v | ((uint32_t)from_float<bf16_t>(hi).v << 16);
+}
+__device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
+    return (uint32_t)from_float<f16_t>(lo).v | ((uint32_t)from_float<f16_t>(hi).v << 16);
+}
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack2_bf16(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) { return pack2_f16(lo, hi); }
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// wave-wide sum (64 lanes); result valid in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int ES> struct uint_of;
+template <> struct uint_of<1> { using type = uint8_t; };
+template <> struct uint_of<2> { using type = uint16_t; };
+template <> struct uint_of<4> { using type = uint32_t; };
+template <> struct uint_of<8> { using type = uint64_t; };
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace ofasr

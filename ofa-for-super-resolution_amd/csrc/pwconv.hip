@@ -1,0 +1,687 @@
+// pwconv.hip -- pointwise (1x1) convolution on in-place weight slices: fwd / dgrad / wgrad on the
+// gfx950 matrix cores.
+//
+// Replaces DynamicPointConv2d.forward (reference ofa/elastic_nn/modules/dynamic_op.py:104-112:
+// `weight[:out,:in].contiguous()` + F.conv2d 1x1) and its autograd.  Per image the op is the GEMM
+//     Y_n[M x P] = W[M x K] . X_n[K x P]          (P = H*W pixels, contiguous in NCHW)
+// fwd: (M,K) = (Cout,Cin); dgrad: (M,K) = (Cin,Cout) with W read transposed in place;
+// wgrad: dW[M x K] = sum_n dY_n[M x P] . X_n[K x P]^T  (the reduction runs over pixels).
+//
+// Roofline: un-fused, the op moves B*(K+M)*P bytes per image for 2*M*K*P flops: 54 flop/B in bf16
+// at (64 <-> 384), far left of the MFMA ridge (~310 flop/B), so the kernels are HBM-bound and are
+// built around the memory system: every activation byte is read once and written once with
+// 16-byte lanes, the weight slice is read in place (leading-dimension stride, no copy), and the
+// MFMA work rides underneath.  fp32 activations use v_mfma_f32_32x32x2_f32 (exact fp32 fma
+// chain, 1/16 of the bf16 rate) and are matrix-bound instead; that path exists for parity.
+//
+// Pixel <-> MFMA-column mapping.  With D[row = channel][col = pixel] the accumulator puts one
+// pixel per lane, which would store 2 (bf16) or 4 bytes per lane.  The MFMA does not care which
+// pixel a column is, so column c of sub-tile t is pixel P*c + t (P = 4 "fan-out", 2 "fan-in"):
+// a lane then owns P adjacent pixels across its P accumulator tiles and stores them with one
+// 8/16-byte access (256/512 contiguous bytes per half-wave).  For 16-bit inputs the matching
+// B operand (8 channels of one pixel per lane) comes from an LDS image of the [channel][pixel]
+// tile whose pixel positions are permuted at staging time, read with ds_read_b64_tr_b16.
+//
+// Two schedules cover the shapes of the MB block (and, slower, any other shape):
+//   fan-out (K <= 64, any M)  expand fwd / project dgrad: the 64-channel X tile is staged once,
+//                             the weight slice lives in LDS for the life of a persistent block,
+//                             waves walk the output-channel blocks.
+//   fan-in  (any K, M <= 64 per pass) project fwd / expand dgrad: K is walked in 64-channel chunks
+//                             with the accumulators resident.
+#include "ofasr_common.h"
+
+namespace ofasr {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int PW_THREADS = 256;
+constexpr int PW_TILE = 128;            // pixels per block tile
+constexpr int XROW16 = 320;             // bytes per channel row of a 16-bit X tile (256 + 64 pad)
+constexpr int XROW32 = 512;             // bytes per channel row of an fp32 X tile
+constexpr int WROW16 = 128;             // bytes per 64-k row of a 16-bit operand tile
+constexpr int WROW32 = 256;             // bytes per 64-k row of an fp32 operand tile
+constexpr size_t PW_MAX_W_LDS = 98304;  // 96 KiB of weights resident in LDS
+
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16_t> {
+    static __device__ __forceinline__ f32x16 run(s16x8 a, s16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                       c, 0, 0, 0);
+    }
+};
+template <> struct Mma16<f16_t> {
+    static __device__ __forceinline__ f32x16 run(s16x8 a, s16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
+                                                      0, 0, 0);
+    }
+};
+
+template <typename T> struct Elem { static constexpr bool is16 = true; static constexpr int xrow = XROW16; static constexpr int wrow = WROW16; };
+template <> struct Elem<float> { static constexpr bool is16 = false; static constexpr int xrow = XROW32; static constexpr int wrow = WROW32; };
+
+// W(m, k) = w[m*sm + k*sk]: fwd reads the slice row-major, dgrad reads it transposed, both in place.
+struct WView {
+    const float* w;
+    long long sm, sk;
+    int M, K;
+};
+
+// ---- operand tile in LDS: [rows][64 k], 16-byte chunks XOR-swizzled so that 16 lanes reading the same
+// chunk column of 16 different rows hit 16 different bank groups (ds_read_b128 conflict-free).
+template <typename T>
+__device__ __forceinline__ int wtile_off(int row, int k) {
+    if constexpr (Elem<T>::is16) return row * WROW16 + ((((k >> 3) ^ ((row >> 1) & 7)) << 4)) + (k & 7) * 2;
+    else return row * WROW32 + ((((k >> 2) ^ (row & 15)) << 4)) + (k & 3) * 4;
+}
+template <typename T>
+__device__ __forceinline__ int wtile_chunk_off(int row, int chunk) {  // chunk = 16-byte unit of the row
+    if constexpr (Elem<T>::is16) return row * WROW16 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    else return row * WROW32 + ((chunk ^ (row & 15)) << 4);
+}
+
+template <typename T>
+__device__ __forceinline__ void lds_store_w(char* base, int off, float v) {
+    if constexpr (Elem<T>::is16) *reinterpret_cast<uint16_t*>(base + off) = from_float<T>(v).v;
+    else *reinterpret_cast<float*>(base + off) = v;
+}
+
+// stage W rows [m0, m0+rows) x k in [k0, k0+64) (zero outside the slice) into one operand tile
+template <typename T>
+__device__ __forceinline__ void stage_w_tile(char* Wt, const WView& wv, int m0, int rows, int k0) {
+    const int tid = threadIdx.x;
+    if (wv.sk == 1) {
+        for (int e = tid; e < rows * 64; e += PW_THREADS) {
+            const int r = e >> 6, k = e & 63;
+            const int m = m0 + r, kk = k0 + k;
+            const float v = (m < wv.M && kk < wv.K) ? wv.w[(long long)m * wv.sm + kk] : 0.f;
+            lds_store_w<T>(Wt, wtile_off<T>(r, k), v);
+        }
+    } else {  // transposed view: consecutive threads walk m (the unit-stride direction)
+        for (int e = tid; e < rows * 64; e += PW_THREADS) {
+            const int k = e / rows, r = e - k * rows;
+            const int m = m0 + r, kk = k0 + k;
+            const float v = (m < wv.M && kk < wv.K) ? wv.w[(long long)m * wv.sm + (long long)kk * wv.sk] : 0.f;
+            lds_store_w<T>(Wt, wtile_off<T>(r, k), v);
+        }
+    }
+}
+
+// ---- X tile staging: channels [k0, k0+64) x pixels [p0, p0+128) of image plane block xn ([K][HW]).
+// PX = pixels per lane (4 fan-out, 2 fan-in).  16-bit position of pixel q in [0,128):
+//   PX=4: 32*(q&3) + (q>>2)            PX=2: 64*(q>>6) + 32*(q&1) + ((q&63)>>1)
+template <int PX>
+__device__ __forceinline__ int pos16(int q) {
+    return PX == 4 ? (32 * (q & 3) + (q >> 2)) : (64 * (q >> 6) + 32 * (q & 1) + ((q & 63) >> 1));
+}
+
+template <typename T, int PX, bool ALIGNED>
+__device__ __forceinline__ void stage_x_tile(char* Xs, const T* __restrict__ xn, int K, int HW, int k0, int p0) {
+    const int tid = threadIdx.x;
+    if constexpr (Elem<T>::is16) {
+        if (ALIGNED) {
+            // 64 rows x 16 chunks of 8 pixels (16 B); HW % 8 == 0 so a chunk is all-in or all-out
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int q = tid + it * PW_THREADS;
+                const int k = q >> 4, m = q & 15;
+                const int px = p0 + 8 * m;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (k0 + k < K && px < HW) v = *reinterpret_cast<const uint4*>(xn + (long long)(k0 + k) * HW + px);
+                char* row = Xs + k * XROW16;
+                if (PX == 4) {
+                    // pixel 8m+i -> position 32*(i&3) + 2m + (i>>2): pairs (i, i+4) are adjacent
+                    uint32_t* r32 = reinterpret_cast<uint32_t*>(row);
+                    r32[(32 * 0 + 2 * m) >> 1] = (v.x & 0xffffu) | (v.z << 16);
+                    r32[(32 * 1 + 2 * m) >> 1] = (v.x >> 16) | (v.z & 0xffff0000u);
+                    r32[(32 * 2 + 2 * m) >> 1] = (v.y & 0xffffu) | (v.w << 16);
+                    r32[(32 * 3 + 2 * m) >> 1] = (v.y >> 16) | (v.w & 0xffff0000u);
+                } else {
+                    // pixel 8m+i -> position 64*(m>>3) + 32*(i&1) + 4*(m&7) + (i>>1)
+                    const int base = 64 * (m >> 3) + 4 * (m & 7);
+                    uint2 ev = make_uint2((v.x & 0xffffu) | (v.y << 16), (v.z & 0xffffu) | (v.w << 16));
+                    uint2 od = make_uint2((v.x >> 16) | (v.y & 0xffff0000u), (v.z >> 16) | (v.w & 0xffff0000u));
+                    *reinterpret_cast<uint2*>(row + (base)*2) = ev;
+                    *reinterpret_cast<uint2*>(row + (base + 32) * 2) = od;
+                }
+            }
+        } else {
+            for (int e = tid; e < 64 * PW_TILE; e += PW_THREADS) {
+                const int k = e >> 7, q = e & 127;
+                const int px = p0 + q;
+                uint16_t v = 0;
+                if (k0 + k < K && px < HW) v = reinterpret_cast<const uint16_t*>(xn)[(long long)(k0 + k) * HW + px];
+                *reinterpret_cast<uint16_t*>(Xs + k * XROW16 + pos16<PX>(q) * 2) = v;
+            }
+        }
+    } else {
+        if (ALIGNED) {
+            // 64 rows x 32 chunks of 4 pixels (16 B); HW % 4 == 0
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int q = tid + it * PW_THREADS;
+                const int k = q >> 5, m = q & 31;
+                const int px = p0 + 4 * m;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (k0 + k < K && px < HW) v = *reinterpret_cast<const uint4*>(xn + (long long)(k0 + k) * HW + px);
+                *reinterpret_cast<uint4*>(Xs + k * XROW32 + m * 16) = v;
+            }
+        } else {
+            for (int e = tid; e < 64 * PW_TILE; e += PW_THREADS) {
+                const int k = e >> 7, q = e & 127;
+                const int px = p0 + q;
+                float v = 0.f;
+                if (k0 + k < K && px < HW) v = reinterpret_cast<const float*>(xn)[(long long)(k0 + k) * HW + px];
+                *reinterpret_cast<float*>(Xs + k * XROW32 + q * 4) = v;
+            }
+        }
+    }
+}
+
+// B fragment (8 channels of one pixel-column per lane) of 32-column sub-tile starting at LDS position
+// `pos0`, k-step s (channels 16s..16s+15), by two transposing reads.
+__device__ __forceinline__ s16x8 read_b_frag16(const char* Xs, int pos0, int s, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int kb = 16 * s + 8 * (g >> 1);
+    const int colb = (pos0 + 16 * (g & 1) + 4 * pp) * 2;
+    const lds_s16x4* p0 = (const lds_s16x4*)(Xs + (kb + q) * XROW16 + colb);
+    const lds_s16x4* p1 = (const lds_s16x4*)(Xs + (kb + 4 + q) * XROW16 + colb);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// row of accumulator register `reg` for lane half h (C/D layout of the 32x32 MFMA)
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// store PX adjacent pixels of one output row
+template <typename T, int PX, bool ALIGNED>
+__device__ __forceinline__ void store_px(T* __restrict__ dst, int px, int HW, const float* v) {
+    if (ALIGNED) {
+        if (px < HW) {
+            if constexpr (Elem<T>::is16) {
+                if (PX == 4) *reinterpret_cast<uint2*>(dst + px) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+                else *reinterpret_cast<uint32_t*>(dst + px) = pack2<T>(v[0], v[1]);
+            } else {
+                if (PX == 4) *reinterpret_cast<float4*>(dst + px) = make_float4(v[0], v[1], v[2], v[3]);
+                else *reinterpret_cast<float2*>(dst + px) = make_float2(v[0], v[1]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < PX; ++t)
+            if (px + t < HW) dst[px + t] = from_float<T>(v[t]);
+    }
+}
+
+// ------------------------------------------------------------------------------------ fan-out
+// K <= 64.  grid.x persistent over pixel tiles, grid.y over M super-blocks of `mrows` rows.
+template <typename T, bool ALIGNED>
+__global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y,
+                                                               int HW, int tiles_per_img, int total_tiles, int mrows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int m_base = blockIdx.y * mrows;
+    const int mloc = min(mrows, wv.M - m_base);
+    const int ncb = (mloc + 31) >> 5;
+    char* Ws = smem;
+    char* Xs = smem + ncb * 32 * Elem<T>::wrow;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int c = lane & 31, h = lane >> 5;
+
+    stage_w_tile<T>(Ws, wv, m_base, ncb * 32, 0);
+
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const int n = tile / tiles_per_img;
+        const int p0 = (tile - n * tiles_per_img) * PW_TILE;
+        const T* xn = x + (long long)n * wv.K * HW;
+        T* yn = y + ((long long)n * wv.M + m_base) * HW;
+        __syncthreads();  // readers of the previous X tile are done (first pass: W tile written)
+        stage_x_tile<T, 4, ALIGNED>(Xs, xn, wv.K, HW, 0, p0);
+        __syncthreads();
+
+        if constexpr (Elem<T>::is16) {
+            s16x8 bf[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bf[t][s] = read_b_frag16(Xs, 32 * t, s, lane);
+            for (int cb = wave; cb < ncb; cb += 4) {
+                const int row = 32 * cb + c;
+                s16x8 af[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    af[s] = *reinterpret_cast<const s16x8*>(Ws + wtile_chunk_off<T>(row, 2 * s + h));
+                f32x16 acc[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = zero16();
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = Mma16<T>::run(af[s], bf[t][s], acc[t]);
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int r = 32 * cb + acc_row(reg, h);
+                    if (r < mloc) {
+                        const float v[4] = {acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]};
+                        store_px<T, 4, ALIGNED>(yn + (long long)r * HW, p0 + 4 * c, HW, v);
+                    }
+                }
+            }
+        } else {
+            for (int cb = wave; cb < ncb; cb += 4) {
+                const int row = 32 * cb + c;
+                f32x16 acc[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = zero16();
+#pragma unroll
+                for (int s4 = 0; s4 < 8; ++s4) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(Ws + wtile_chunk_off<T>(row, 8 * h + s4));
+                    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                    for (int ss = 0; ss < 4; ++ss) {
+                        const int k = 32 * h + 4 * s4 + ss;  // MFMA k-slot h of step s <-> channel 32h + s
+                        const float4 b4 = *reinterpret_cast<const float4*>(Xs + k * XROW32 + c * 16);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b4.x, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b4.y, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b4.z, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b4.w, acc[3], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int r = 32 * cb + acc_row(reg, h);
+                    if (r < mloc) {
+                        const float v[4] = {acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]};
+                        store_px<T, 4, ALIGNED>(yn + (long long)r * HW, p0 + 4 * c, HW, v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------- fan-in
+// any K (<= kchunks*64 resident in LDS), 64 output rows per grid.y pass.
+// wave w: output row block cb = w&1, pixel half hh = w>>1 (64 pixels, 2 per lane).
+template <typename T, bool ALIGNED>
+__global__ void __launch_bounds__(PW_THREADS) pw_fanin_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y,
+                                                              int HW, int tiles_per_img, int total_tiles, int kchunks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int m_base = blockIdx.y * 64;
+    const int mloc = min(64, wv.M - m_base);
+    constexpr int WT = 64 * Elem<T>::wrow;  // bytes of one [64][64] operand tile
+    char* Ws = smem;
+    char* Xs = smem + (size_t)kchunks * WT;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int c = lane & 31, h = lane >> 5;
+    const int cb = wave & 1, hh = wave >> 1;
+
+    for (int kc = 0; kc < kchunks; ++kc) stage_w_tile<T>(Ws + (size_t)kc * WT, wv, m_base, 64, kc * 64);
+
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const int n = tile / tiles_per_img;
+        const int p0 = (tile - n * tiles_per_img) * PW_TILE;
+        const T* xn = x + (long long)n * wv.K * HW;
+        T* yn = y + ((long long)n * wv.M + m_base) * HW;
+        f32x16 acc[2];
+        acc[0] = zero16();
+        acc[1] = zero16();
+        const int row = 32 * cb + c;
+        for (int kc = 0; kc < kchunks; ++kc) {
+            __syncthreads();
+            stage_x_tile<T, 2, ALIGNED>(Xs, xn, wv.K, HW, kc * 64, p0);
+            __syncthreads();
+            const char* Wt = Ws + (size_t)kc * WT;
+            if constexpr (Elem<T>::is16) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const s16x8 af = *reinterpret_cast<const s16x8*>(Wt + wtile_chunk_off<T>(row, 2 * s + h));
+                    const s16x8 b0 = read_b_frag16(Xs, 64 * hh, s, lane);
+                    const s16x8 b1 = read_b_frag16(Xs, 64 * hh + 32, s, lane);
+                    acc[0] = Mma16<T>::run(af, b0, acc[0]);
+                    acc[1] = Mma16<T>::run(af, b1, acc[1]);
+                }
+            } else {
+#pragma unroll
+                for (int s4 = 0; s4 < 8; ++s4) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(Wt + wtile_chunk_off<T>(row, 8 * h + s4));
+                    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                    for (int ss = 0; ss < 4; ++ss) {
+                        const int k = 32 * h + 4 * s4 + ss;
+                        const float2 b2 = *reinterpret_cast<const float2*>(Xs + k * XROW32 + (64 * hh + 2 * c) * 4);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b2.x, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b2.y, acc[1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int r = 32 * cb + acc_row(reg, h);
+            if (r < mloc) {
+                const float v[2] = {acc[0][reg], acc[1][reg]};
+                store_px<T, 2, ALIGNED>(yn + (long long)r * HW, p0 + 64 * hh + 2 * c, HW, v);
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------- wgrad
+// out(r, s) = sum_{n,p} R[n][r][p] * S[n][s][p];  R: [N][MR][HW], S: [N][NS][HW].
+// block: 64 R-rows x 64 S-rows, one 32x32 MFMA tile per wave; grid.z splits the (n, pixel-chunk) range;
+// partials [z][MR][NS] fp32 are summed by pw_wgrad_reduce_kernel in a fixed order (deterministic).
+template <typename T, bool ALIGNED>
+__device__ __forceinline__ void stage_rows64(char* Lt, const T* __restrict__ base, int rows_total, int r0, int HW,
+                                             int p0) {
+    // [64 rows][64 px] -> operand tile (row-major, px = k)
+    const int tid = threadIdx.x;
+    if constexpr (Elem<T>::is16) {
+        if (ALIGNED) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int q = tid + it * PW_THREADS;  // 64 rows x 8 chunks
+                const int r = q >> 3, ch = q & 7;
+                const int px = p0 + 8 * ch;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (r0 + r < rows_total && px < HW)
+                    v = *reinterpret_cast<const uint4*>(base + (long long)(r0 + r) * HW + px);
+                *reinterpret_cast<uint4*>(Lt + wtile_chunk_off<T>(r, ch)) = v;
+            }
+        } else {
+            for (int e = tid; e < 64 * 64; e += PW_THREADS) {
+                const int r = e >> 6, k = e & 63;
+                uint16_t v = 0;
+                if (r0 + r < rows_total && p0 + k < HW)
+                    v = reinterpret_cast<const uint16_t*>(base)[(long long)(r0 + r) * HW + p0 + k];
+                *reinterpret_cast<uint16_t*>(Lt + wtile_off<T>(r, k)) = v;
+            }
+        }
+    } else {
+        if (ALIGNED) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int q = tid + it * PW_THREADS;  // 64 rows x 16 chunks
+                const int r = q >> 4, ch = q & 15;
+                const int px = p0 + 4 * ch;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (r0 + r < rows_total && px < HW)
+                    v = *reinterpret_cast<const uint4*>(base + (long long)(r0 + r) * HW + px);
+                *reinterpret_cast<uint4*>(Lt + wtile_chunk_off<T>(r, ch)) = v;
+            }
+        } else {
+            for (int e = tid; e < 64 * 64; e += PW_THREADS) {
+                const int r = e >> 6, k = e & 63;
+                float v = 0.f;
+                if (r0 + r < rows_total && p0 + k < HW)
+                    v = reinterpret_cast<const float*>(base)[(long long)(r0 + r) * HW + p0 + k];
+                *reinterpret_cast<float*>(Lt + wtile_off<T>(r, k)) = v;
+            }
+        }
+    }
+}
+
+template <typename T, bool ALIGNED>
+__global__ void __launch_bounds__(PW_THREADS) pw_wgrad_kernel(const T* __restrict__ R, const T* __restrict__ S,
+                                                              float* __restrict__ part, int MR, int NS, int HW,
+                                                              int chunks_per_img, int total_chunks,
+                                                              int chunks_per_split) {
+    __shared__ __attribute__((aligned(16))) char Rt[64 * Elem<T>::wrow];
+    __shared__ __attribute__((aligned(16))) char St[64 * Elem<T>::wrow];
+    const int r0 = blockIdx.x * 64, s0 = blockIdx.y * 64, z = blockIdx.z;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int c = lane & 31, h = lane >> 5;
+    const int rb = wave & 1, sb = wave >> 1;
+    f32x16 acc = zero16();
+    const int q_lo = z * chunks_per_split;
+    const int q_hi = min(total_chunks, q_lo + chunks_per_split);
+    for (int q = q_lo; q < q_hi; ++q) {
+        const int n = q / chunks_per_img;
+        const int p0 = (q - n * chunks_per_img) * 64;
+        __syncthreads();
+        stage_rows64<T, ALIGNED>(Rt, R + (long long)n * MR * HW, MR, r0, HW, p0);
+        stage_rows64<T, ALIGNED>(St, S + (long long)n * NS * HW, NS, s0, HW, p0);
+        __syncthreads();
+        if constexpr (Elem<T>::is16) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const s16x8 af = *reinterpret_cast<const s16x8*>(Rt + wtile_chunk_off<T>(32 * rb + c, 2 * s + h));
+                const s16x8 bf = *reinterpret_cast<const s16x8*>(St + wtile_chunk_off<T>(32 * sb + c, 2 * s + h));
+                acc = Mma16<T>::run(af, bf, acc);
+            }
+        } else {
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(Rt + wtile_chunk_off<T>(32 * rb + c, 8 * h + s4));
+                const float4 b4 = *reinterpret_cast<const float4*>(St + wtile_chunk_off<T>(32 * sb + c, 8 * h + s4));
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+            }
+        }
+    }
+    // D[row = R row][col = S row]: lane holds column c, 16 rows
+    float* pz = part + (long long)z * MR * NS;
+    const int sc = s0 + 32 * sb + c;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int rr = r0 + 32 * rb + acc_row(reg, h);
+        if (rr < MR && sc < NS) pz[(long long)rr * NS + sc] = acc[reg];
+    }
+}
+
+__global__ void __launch_bounds__(256) pw_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                              int MR, int NS, int nsplit, long long sr, long long ss) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long tot = (long long)MR * NS;
+    if (idx >= tot) return;
+    float a = 0.f;
+    for (int z = 0; z < nsplit; ++z) a += part[(long long)z * tot + idx];
+    const long long r = idx / NS, s = idx - r * NS;
+    dw[r * sr + s * ss] = a;
+}
+
+struct WgradPlan {
+    int chunks_per_img, total_chunks, nsplit, chunks_per_split, MR, NS;
+};
+
+static WgradPlan wgrad_plan(int64_t N, int64_t Cin, int64_t Cout, int64_t HW) {
+    WgradPlan p;
+    p.MR = (int)(Cout >= Cin ? Cout : Cin);
+    p.NS = (int)(Cout >= Cin ? Cin : Cout);
+    p.chunks_per_img = (int)cdiv(HW, 64);
+    p.total_chunks = (int)(N * p.chunks_per_img);
+    const int64_t tiles = cdiv(p.MR, 64) * cdiv(p.NS, 64);
+    int64_t want = 512 / (tiles > 0 ? tiles : 1);
+    if (want < 1) want = 1;
+    if (want > p.total_chunks) want = p.total_chunks;
+    if (want < 1) want = 1;
+    p.chunks_per_split = (int)cdiv(p.total_chunks, want);
+    if (p.chunks_per_split < 1) p.chunks_per_split = 1;
+    p.nsplit = (int)cdiv(p.total_chunks, p.chunks_per_split);
+    if (p.nsplit < 1) p.nsplit = 1;
+    return p;
+}
+
+template <typename F>
+static void allow_big_lds(F kernel) {
+    // one-time per kernel: let a block ask for more than the default dynamic-LDS limit (gfx950: 160 KiB/CU)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+}
+
+static bool aligned_for(const void* a, const void* b, int64_t HW, bool is16) {
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b);
+    return (bits & 15) == 0 && (HW % (is16 ? 8 : 4)) == 0;
+}
+
+template <typename T>
+static int launch_gemm(const char* name, const void* x, WView wv, void* y, int64_t N, int64_t HW, hipStream_t st) {
+    constexpr bool is16 = Elem<T>::is16;
+    const bool al = aligned_for(x, y, HW, is16);
+    const int tiles_per_img = (int)cdiv(HW, PW_TILE);
+    const int64_t total64 = N * tiles_per_img;
+    OFASR_REQUIRE(total64 <= INT32_MAX, OFASR_ERR_UNSUPPORTED, "%s: too many pixel tiles", name);
+    const int total_tiles = (int)total64;
+    const int xbytes = 64 * Elem<T>::xrow;
+    if (wv.K <= 64) {
+        // fan-out: M super-blocks so that the resident weight tile stays <= 96 KiB
+        const int max_rows = (int)(PW_MAX_W_LDS / Elem<T>::wrow);  // 768 (16-bit) / 384 (fp32)
+        const int mrows = wv.M <= max_rows ? ((wv.M + 31) / 32) * 32 : max_rows;
+        const int gy = (int)cdiv(wv.M, mrows);
+        const size_t lds = (size_t)mrows * Elem<T>::wrow + xbytes;
+        const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+        int gx = 256 * per_cu / gy;
+        if (gx < 1) gx = 1;
+        if (gx > total_tiles) gx = total_tiles;
+        static const bool once_fo = (allow_big_lds(pw_fanout_kernel<T, true>), allow_big_lds(pw_fanout_kernel<T, false>), true);
+        (void)once_fo;
+        if (al)
+            hipLaunchKernelGGL((pw_fanout_kernel<T, true>), dim3(gx, gy), dim3(PW_THREADS), lds, st, (const T*)x, wv,
+                               (T*)y, (int)HW, tiles_per_img, total_tiles, mrows);
+        else
+            hipLaunchKernelGGL((pw_fanout_kernel<T, false>), dim3(gx, gy), dim3(PW_THREADS), lds, st, (const T*)x, wv,
+                               (T*)y, (int)HW, tiles_per_img, total_tiles, mrows);
+    } else {
+        const int kchunks = (int)cdiv(wv.K, 64);
+        const size_t wbytes = (size_t)kchunks * 64 * Elem<T>::wrow;
+        OFASR_REQUIRE(wbytes <= PW_MAX_W_LDS, OFASR_ERR_UNSUPPORTED,
+                      "%s: reduction width K=%d needs %zu B of LDS weights (> %zu)", name, wv.K, wbytes,
+                      (size_t)PW_MAX_W_LDS);
+        const int gy = (int)cdiv(wv.M, 64);
+        const size_t lds = wbytes + xbytes;
+        const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+        int gx = 256 * per_cu / gy;
+        if (gx < 1) gx = 1;
+        if (gx > total_tiles) gx = total_tiles;
+        static const bool once_fi = (allow_big_lds(pw_fanin_kernel<T, true>), allow_big_lds(pw_fanin_kernel<T, false>), true);
+        (void)once_fi;
+        if (al)
+            hipLaunchKernelGGL((pw_fanin_kernel<T, true>), dim3(gx, gy), dim3(PW_THREADS), lds, st, (const T*)x, wv,
+                               (T*)y, (int)HW, tiles_per_img, total_tiles, kchunks);
+        else
+            hipLaunchKernelGGL((pw_fanin_kernel<T, false>), dim3(gx, gy), dim3(PW_THREADS), lds, st, (const T*)x, wv,
+                               (T*)y, (int)HW, tiles_per_img, total_tiles, kchunks);
+    }
+    return check_launch(name);
+}
+
+static int gemm_entry(const char* name, const void* x, WView wv, void* y, int64_t N, int64_t HW, int dtype,
+                      void* stream) {
+    hipStream_t st = as_stream(stream);
+    switch (dtype) {
+        case OFASR_F32: return launch_gemm<float>(name, x, wv, y, N, HW, st);
+        case OFASR_F16: return launch_gemm<f16_t>(name, x, wv, y, N, HW, st);
+        default: return launch_gemm<bf16_t>(name, x, wv, y, N, HW, st);
+    }
+}
+
+static int check_pw_args(const char* name, const void* a, const void* b, const void* c, int64_t ldw, int64_t N,
+                         int64_t Cin, int64_t Cout, int64_t HW, int dtype) {
+    OFASR_REQUIRE(a && b && c, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(N >= 0 && Cin > 0 && Cout > 0 && HW >= 0, OFASR_ERR_INVALID_ARG,
+                  "%s: bad shape N=%lld Cin=%lld Cout=%lld HW=%lld", name, (long long)N, (long long)Cin,
+                  (long long)Cout, (long long)HW);
+    OFASR_REQUIRE(ldw >= Cin, OFASR_ERR_INVALID_ARG, "%s: ldw=%lld < Cin=%lld", name, (long long)ldw, (long long)Cin);
+    OFASR_REQUIRE(dtype == OFASR_F32 || dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_INVALID_ARG,
+                  "%s: bad dtype %d", name, dtype);
+    OFASR_REQUIRE(Cin <= 65536 && Cout <= 65536 && HW <= (1 << 30) && N <= (1 << 24), OFASR_ERR_UNSUPPORTED,
+                  "%s: dimension too large", name);
+    return OFASR_OK;
+}
+
+template <typename T>
+static int launch_wgrad(const char* name, const void* dy, const void* x, float* dw, int64_t ldw, int64_t N, int64_t Cin,
+                        int64_t Cout, int64_t HW, float* ws, hipStream_t st) {
+    const WgradPlan p = wgrad_plan(N, Cin, Cout, HW);
+    const bool big_is_dy = Cout >= Cin;
+    const T* R = (const T*)(big_is_dy ? dy : x);
+    const T* S = (const T*)(big_is_dy ? x : dy);
+    // out(r, s): r indexes the big operand's channels
+    const long long sr = big_is_dy ? ldw : 1, ss = big_is_dy ? 1 : ldw;
+    const bool al = aligned_for(dy, x, HW, Elem<T>::is16);
+    dim3 grid((unsigned)cdiv(p.MR, 64), (unsigned)cdiv(p.NS, 64), (unsigned)p.nsplit);
+    if (al)
+        hipLaunchKernelGGL((pw_wgrad_kernel<T, true>), grid, dim3(PW_THREADS), 0, st, R, S, ws, p.MR, p.NS, (int)HW,
+                           p.chunks_per_img, p.total_chunks, p.chunks_per_split);
+    else
+        hipLaunchKernelGGL((pw_wgrad_kernel<T, false>), grid, dim3(PW_THREADS), 0, st, R, S, ws, p.MR, p.NS, (int)HW,
+                           p.chunks_per_img, p.total_chunks, p.chunks_per_split);
+    int rc = check_launch(name);
+    if (rc) return rc;
+    const long long tot = (long long)p.MR * p.NS;
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, st, ws, dw, p.MR, p.NS,
+                       p.nsplit, sr, ss);
+    return check_launch(name);
+}
+
+}  // namespace ofasr
+
+using namespace ofasr;
+
+OFASR_EXPORT int ofasr_pwconv_fwd(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin,
+                                  int64_t Cout, int64_t HW, int dtype, void* stream) {
+    const char* name = "ofasr_pwconv_fwd";
+    int rc = check_pw_args(name, x, w, y, ldw, N, Cin, Cout, HW, dtype);
+    if (rc) return rc;
+    if (N * HW == 0) return OFASR_OK;
+    WView wv{w, ldw, 1, (int)Cout, (int)Cin};
+    return gemm_entry(name, x, wv, y, N, HW, dtype, stream);
+}
+
+OFASR_EXPORT int ofasr_pwconv_dgrad(const void* dy, const float* w, int64_t ldw, void* dx, int64_t N, int64_t Cin,
+                                    int64_t Cout, int64_t HW, int dtype, void* stream) {
+    const char* name = "ofasr_pwconv_dgrad";
+    int rc = check_pw_args(name, dy, w, dx, ldw, N, Cin, Cout, HW, dtype);
+    if (rc) return rc;
+    if (N * HW == 0) return OFASR_OK;
+    WView wv{w, 1, ldw, (int)Cin, (int)Cout};  // rows = input channels, reduction over output channels
+    return gemm_entry(name, dy, wv, dx, N, HW, dtype, stream);
+}
+
+OFASR_EXPORT size_t ofasr_pwconv_wgrad_workspace(int64_t N, int64_t Cin, int64_t Cout, int64_t HW) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return 0;
+    const WgradPlan p = wgrad_plan(N, Cin, Cout, HW);
+    return (size_t)p.nsplit * (size_t)p.MR * (size_t)p.NS * sizeof(float);
+}
+
+OFASR_EXPORT int ofasr_pwconv_wgrad(const void* dy, const void* x, float* dw, int64_t ldw, int64_t N, int64_t Cin,
+                                    int64_t Cout, int64_t HW, int dtype, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    const char* name = "ofasr_pwconv_wgrad";
+    int rc = check_pw_args(name, dy, x, dw, ldw, N, Cin, Cout, HW, dtype);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    if (N * HW == 0) {
+        // empty reduction: the slice gradient is zero
+        for (int64_t co = 0; co < Cout; ++co) {
+            hipError_t e = hipMemsetAsync(dw + co * ldw, 0, (size_t)Cin * sizeof(float), st);
+            OFASR_REQUIRE(e == hipSuccess, OFASR_ERR_LAUNCH, "%s: memset failed", name);
+        }
+        return OFASR_OK;
+    }
+    const size_t need = ofasr_pwconv_wgrad_workspace(N, Cin, Cout, HW);
+    OFASR_REQUIRE(workspace && workspace_bytes >= need, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B",
+                  name, workspace_bytes, need);
+    float* ws = (float*)workspace;
+    switch (dtype) {
+        case OFASR_F32: return launch_wgrad<float>(name, dy, x, dw, ldw, N, Cin, Cout, HW, ws, st);
+        case OFASR_F16: return launch_wgrad<f16_t>(name, dy, x, dw, ldw, N, Cin, Cout, HW, ws, st);
+        default: return launch_wgrad<bf16_t>(name, dy, x, dw, ldw, N, Cin, Cout, HW, ws, st);
+    }
+}

@@ -1,0 +1,248 @@
+"""torch.autograd bindings of the HIP hot-path kernels (C ABI: include/ofasr.h via _C.py).
+
+Each Function replaces one ATen call site of the reference (file:line in the docstrings) with a
+hand-written gfx950 kernel for forward AND backward.  PyTorch is plumbing here: it owns device
+memory, the stream and the autograd graph; all arithmetic of these ops happens in
+csrc/*.hip.  There is no CPU / eager fallback: tensors must live on the GPU.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _C
+
+_DT = {torch.float32: _C.F32, torch.float16: _C.F16, torch.bfloat16: _C.BF16}
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise _C.OfasrError("unsupported activation dtype %s (f32/f16/bf16 only)" % t.dtype)
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _C.OfasrError(
+                "OFA-SR hot-path ops run only on the MI355X HIP kernels: got a %s tensor (no CPU fallback)" % t.device)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _ws(nbytes, device):
+    n = max(int(nbytes), 16)
+    t = torch.empty(n, dtype=torch.uint8, device=device)
+    return t, ctypes.c_void_p(t.data_ptr()), ctypes.c_size_t(n)
+
+
+def _f32_param(w):
+    if w.dtype != torch.float32:
+        raise _C.OfasrError("weights / filters are fp32 master copies (got %s)" % w.dtype)
+    return w
+
+
+# ------------------------------------------------------------------------------- PixelShuffle
+def _shuffle_raw(x, r, inverse):
+    _gpu(x)
+    x = x.contiguous()
+    N, Cx, Hx, Wx = x.shape
+    if inverse:
+        if Hx % r or Wx % r:
+            raise _C.OfasrError("pixel_unshuffle: spatial size %dx%d not divisible by %d" % (Hx, Wx, r))
+        C, H, W = Cx, Hx // r, Wx // r
+        y = torch.empty((N, C * r * r, H, W), dtype=x.dtype, device=x.device)
+        fn = _C.lib().ofasr_pixel_unshuffle
+    else:
+        if Cx % (r * r):
+            raise _C.OfasrError("pixel_shuffle: channels %d not divisible by %d" % (Cx, r * r))
+        C, H, W = Cx // (r * r), Hx, Wx
+        y = torch.empty((N, C, H * r, W * r), dtype=x.dtype, device=x.device)
+        fn = _C.lib().ofasr_pixel_shuffle
+    _C.check(fn(_p(x), _p(y), N, C, H, W, r, x.element_size(), _stream()),
+             "pixel_unshuffle" if inverse else "pixel_shuffle")
+    return y
+
+
+class PixelShuffleFn(Function):
+    """nn.PixelShuffle(r) (reference ofa/utils.py:309-310); backward is the inverse permutation."""
+
+    @staticmethod
+    def forward(ctx, x, r):
+        ctx.r = r
+        return _shuffle_raw(x, r, False)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return _shuffle_raw(dy, ctx.r, True), None
+
+
+class PixelUnshuffleFn(Function):
+    """pixel_unshuffle (reference ofa/utils.py:383-397, a one-hot strided conv there)."""
+
+    @staticmethod
+    def forward(ctx, x, r):
+        ctx.r = r
+        return _shuffle_raw(x, r, True)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return _shuffle_raw(dy, ctx.r, False), None
+
+
+def pixel_shuffle(x, r=2):
+    return PixelShuffleFn.apply(x, r)
+
+
+def pixel_unshuffle(x, r=2):
+    return PixelUnshuffleFn.apply(x, r)
+
+
+# --------------------------------------------------------------------------- kernel transform
+def _kt_args(chain, mats):
+    ks = (ctypes.c_int * len(chain))(*chain)
+    n = len(chain) - 1
+    arr = (ctypes.c_void_p * max(n, 1))(*([m.data_ptr() for m in mats] if mats else [None] * max(n, 1)))
+    return ks, n, arr
+
+
+class KTransformFn(Function):
+    """DynamicSeparableConv2d.get_active_filter (reference dynamic_op.py:46-71).
+
+    forward(w_max [Cmax,1,kmax,kmax], C, chain (kmax, ..., K), transform, *mats) -> f [C,1,K,K]
+    `mats[s]` is the '%dto%d_matrix' of chain step s (only when transform and K < kmax).
+    backward: dense dw_max (zeros outside rows < C / the crop window) and one gradient per walked
+    matrix; matrices of steps not walked are not inputs here, so their .grad stays None."""
+
+    @staticmethod
+    def forward(ctx, w_max, C, chain, transform, *mats):
+        _gpu(w_max, *mats)
+        w = _f32_param(w_max).contiguous()
+        mats = [_f32_param(m).contiguous() for m in mats]
+        K = chain[-1]
+        f = torch.empty((C, 1, K, K), dtype=torch.float32, device=w.device)
+        ks, n, arr = _kt_args(chain, mats)
+        _C.check(_C.lib().ofasr_ktransform_fwd(_p(w), ks, n, arr, 1 if transform else 0, _p(f), C, _stream()),
+                 "ktransform_fwd")
+        ctx.save_for_backward(w, *mats)
+        ctx.meta = (C, tuple(chain), bool(transform))
+        return f
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, df):
+        w, *mats = ctx.saved_tensors
+        C, chain, transform = ctx.meta
+        df = df.contiguous()
+        dw = torch.zeros_like(w)
+        dmats = [torch.empty_like(m) for m in mats]
+        ks, n, arr = _kt_args(chain, mats)
+        darr = (ctypes.c_void_p * max(n, 1))(*([d.data_ptr() for d in dmats] if dmats else [None] * max(n, 1)))
+        need = _C.lib().ofasr_ktransform_bwd_workspace(ks, n, C) if (transform and mats) else 0
+        wst, wsp, wsn = _ws(need, w.device)
+        _C.check(_C.lib().ofasr_ktransform_bwd(_p(w), ks, n, arr, 1 if transform else 0, _p(df), _p(dw), darr, C,
+                                               wsp, wsn, _stream()), "ktransform_bwd")
+        return (dw, None, None, None) + tuple(dmats)
+
+
+# ------------------------------------------------------------------------------- depthwise conv
+class DWConvFn(Function):
+    """F.conv2d(x, f, groups=C, padding=k//2) of DynamicSeparableConv2d.forward (dynamic_op.py:79-83)."""
+
+    @staticmethod
+    def forward(ctx, x, f):
+        _gpu(x, f)
+        x = x.contiguous()
+        f = _f32_param(f).contiguous()
+        N, C, H, W = x.shape
+        K = f.shape[-1]
+        if f.shape[0] != C:
+            raise _C.OfasrError("dwconv: filter has %d channels, input has %d" % (f.shape[0], C))
+        y = torch.empty_like(x)
+        _C.check(_C.lib().ofasr_dwconv_fwd(_p(x), _p(f), _p(y), N, C, H, W, K, _dt(x), _stream()), "dwconv_fwd")
+        ctx.save_for_backward(x, f)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, f = ctx.saved_tensors
+        N, C, H, W = x.shape
+        K = f.shape[-1]
+        dy = dy.contiguous()
+        L = _C.lib()
+        dx = df = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _C.check(L.ofasr_dwconv_dgrad(_p(dy), _p(f), _p(dx), N, C, H, W, K, _dt(x), _stream()), "dwconv_dgrad")
+        if ctx.needs_input_grad[1]:
+            df = torch.empty_like(f)
+            wst, wsp, wsn = _ws(L.ofasr_dwconv_wgrad_workspace(N, C, H, W, K), x.device)
+            _C.check(L.ofasr_dwconv_wgrad(_p(dy), _p(x), _p(df), N, C, H, W, K, _dt(x), wsp, wsn, _stream()),
+                     "dwconv_wgrad")
+        return dx, df
+
+
+def dwconv(x, f):
+    return DWConvFn.apply(x, f)
+
+
+# ------------------------------------------------------------------------------- pointwise conv
+class PWConvFn(Function):
+    """DynamicPointConv2d.forward (reference dynamic_op.py:104-112): the [:cout, :cin] slice of the
+    max-size 1x1 weight is read IN PLACE (row stride = weight.shape[1]); backward returns a dense
+    gradient of the full parameter with exact zeros outside the slice."""
+
+    @staticmethod
+    def forward(ctx, x, w_full, cout):
+        _gpu(x, w_full)
+        x = x.contiguous()
+        w = _f32_param(w_full).contiguous()
+        if w.dim() != 4 or w.shape[2] != 1 or w.shape[3] != 1:
+            raise _C.OfasrError("pwconv: weight must be [Cout_max, Cin_max, 1, 1], got %s" % (tuple(w.shape),))
+        N, Cin, H, W = x.shape
+        ldw = w.shape[1]
+        if Cin > ldw or cout > w.shape[0]:
+            raise _C.OfasrError("pwconv: slice [%d,%d] exceeds weight %s" % (cout, Cin, tuple(w.shape)))
+        y = torch.empty((N, cout, H, W), dtype=x.dtype, device=x.device)
+        _C.check(_C.lib().ofasr_pwconv_fwd(_p(x), _p(w), ldw, _p(y), N, Cin, cout, H * W, _dt(x), _stream()),
+                 "pwconv_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.cout = cout
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, Cin, H, W = x.shape
+        cout, ldw = ctx.cout, w.shape[1]
+        dy = dy.contiguous()
+        L = _C.lib()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _C.check(L.ofasr_pwconv_dgrad(_p(dy), _p(w), ldw, _p(dx), N, Cin, cout, H * W, _dt(x), _stream()),
+                     "pwconv_dgrad")
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            wst, wsp, wsn = _ws(L.ofasr_pwconv_wgrad_workspace(N, Cin, cout, H * W), x.device)
+            _C.check(L.ofasr_pwconv_wgrad(_p(dy), _p(x), _p(dw), ldw, N, Cin, cout, H * W, _dt(x), wsp, wsn,
+                                          _stream()), "pwconv_wgrad")
+        return dx, dw, None
+
+
+def pwconv(x, w_full, cout):
+    return PWConvFn.apply(x, w_full, cout)
