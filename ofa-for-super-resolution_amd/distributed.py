@@ -1,0 +1,117 @@
+"""Data-parallel gradient exchange for progressive-shrinking training: one process per GPU, ONE flat
+all-reduce (RCCL over xGMI; `nccl` backend on ROCm, `gloo` on CPU for tests) per optimizer step.
+
+Replaces the reference's single-process nn.DataParallel (sr_run_manager.py:197-198: per-step
+parameter broadcast + input scatter + output gather + gradient reduce-to-device-0, all behind one
+GIL) and the Horovod per-parameter all-reduce of the ImageNet path (distributed_run_manager.py:72-75).
+
+Design:
+  * every parameter's .grad is a VIEW into one contiguous fp32 buffer (2,160,422 elements = 8.64 MB
+    for the S4 supernet), so autograd accumulates straight into the bucket -- no gather/scatter
+    copies -- and the exchange is a single collective;
+  * elastic depth / kernel size leave some parameters without a gradient.  The reference's Adam
+    skips such parameters entirely (grad is None), so after the all-reduce the untouched
+    parameters get .grad = None again.  All ranks draw the same sub-network (shared seed,
+    progressive_shrinking.py:164), hence the same untouched set; their bucket slices are zeros;
+  * BN statistics stay local to a rank, like the reference's DataParallel replicas (no SyncBN).
+"""
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def broadcast_module(module, src=0):
+    """make every rank start from rank `src`'s parameters and buffers (one flat broadcast each)."""
+    if not is_distributed():
+        return
+    with torch.no_grad():
+        for tensors in (list(module.parameters()), [b for b in module.buffers() if b.is_floating_point()]):
+            if not tensors:
+                continue
+            flat = torch.cat([t.detach().reshape(-1).float() for t in tensors])
+            dist.broadcast(flat, src)
+            off = 0
+            for t in tensors:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
+        for b in module.buffers():
+            if not b.is_floating_point():
+                dist.broadcast(b, src)
+
+
+class FlatGradReducer(object):
+    """owns the flat gradient bucket of `params` and the single all-reduce over it.
+
+        reducer = FlatGradReducer(net.parameters())
+        for batch in loader:
+            reducer.prepare()                 # instead of optimizer.zero_grad()
+            for _ in range(dynamic_batch_size):
+                loss(...).backward()          # accumulates into the bucket
+            reducer.reduce()                  # all-reduce + average; untouched params -> grad None
+            optimizer.step()
+    """
+
+    def __init__(self, params, process_group=None):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGradReducer needs at least one trainable parameter")
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise ValueError("master weights are fp32")
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.group = process_group
+        self._touched = [False] * len(self.params)
+        self._handles = [p.register_post_accumulate_grad_hook(self._make_hook(i))
+                         for i, p in enumerate(self.params)]
+
+    def _make_hook(self, i):
+        def hook(_param):
+            self._touched[i] = True
+        return hook
+
+    @property
+    def nbytes(self):
+        return self.flat.numel() * 4
+
+    def prepare(self):
+        """zero the bucket and point every .grad at its slice (replaces optimizer.zero_grad())."""
+        self.flat.zero_()
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            p.grad = v
+            self._touched[i] = False
+
+    def touched_mask(self):
+        return list(self._touched)
+
+    def reduce(self, average=True):
+        """one all-reduce over the whole bucket; afterwards parameters that received no gradient in
+        this step have .grad None (so Adam skips them, as in the reference)."""
+        if is_distributed():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if average:
+                self.flat.div_(dist.get_world_size(self.group))
+        for p, t in zip(self.params, self._touched):
+            if not t:
+                p.grad = None
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

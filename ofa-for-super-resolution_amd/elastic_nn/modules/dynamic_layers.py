@@ -1,0 +1,130 @@
+"""DynamicMBConvLayer -- the elastic inverted-bottleneck block of the OFA-SR supernet, on the HIP
+operators of dynamic_op.py.
+
+Drop-in for reference ofa/elastic_nn/modules/dynamic_layers.py:14-199: same constructor, same
+sub-module / parameter names (=> same state-dict keys), same `active_*` attribute protocol,
+`get_active_subnet` and `re_organize_middle_weights`.  DynamicConvLayer / DynamicLinearLayer are
+unused by the SR nets and out of scope.
+"""
+import copy
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from ...layers import MBInvertedConvLayer
+from ...utils import MyModule, build_activation, get_net_device, int2list, make_divisible
+from ..utils import adjust_bn_according_to_idx, copy_bn
+from .dynamic_op import DynamicBatchNorm2d, DynamicPointConv2d, DynamicSeparableConv2d
+
+
+def _conv_bn_act(conv, bn, act_func):
+    mods = [("conv", conv), ("bn", bn)]
+    act = build_activation(act_func, inplace=True)
+    if act is not None:
+        mods.append(("act", act))
+    return nn.Sequential(OrderedDict(mods))
+
+
+class DynamicMBConvLayer(MyModule):
+    """expand 1x1 (C_in -> mid) -> BN -> act -> depthwise kxk -> BN -> act -> project 1x1 (mid -> C_out) -> BN
+    with mid = make_divisible(round(C_in * active_expand_ratio), 8) and k = active_kernel_size."""
+
+    def __init__(self, in_channel_list, out_channel_list, kernel_size_list=3, expand_ratio_list=6, stride=1,
+                 act_func="relu6", use_se=False):
+        super().__init__()
+        self.in_channel_list = in_channel_list
+        self.out_channel_list = out_channel_list
+        self.kernel_size_list = int2list(kernel_size_list, 1)
+        self.expand_ratio_list = int2list(expand_ratio_list, 1)
+        self.stride = stride
+        self.act_func = act_func
+        self.use_se = use_se
+        if use_se:
+            raise NotImplementedError("squeeze-excite is classification-only (se_stages all False in the SR nets)")
+
+        c_in, c_out = max(self.in_channel_list), max(self.out_channel_list)
+        mid_max = round(c_in * max(self.expand_ratio_list))
+        if max(self.expand_ratio_list) == 1:
+            self.inverted_bottleneck = None
+        else:
+            self.inverted_bottleneck = _conv_bn_act(DynamicPointConv2d(c_in, mid_max), DynamicBatchNorm2d(mid_max),
+                                                    act_func)
+        self.depth_conv = _conv_bn_act(DynamicSeparableConv2d(mid_max, self.kernel_size_list, stride),
+                                       DynamicBatchNorm2d(mid_max), act_func)
+        self.point_linear = _conv_bn_act(DynamicPointConv2d(mid_max, c_out), DynamicBatchNorm2d(c_out), None)
+
+        self.active_kernel_size = max(self.kernel_size_list)
+        self.active_expand_ratio = max(self.expand_ratio_list)
+        self.active_out_channel = c_out
+
+    def active_middle_channel(self, in_channel):
+        return make_divisible(round(in_channel * self.active_expand_ratio), 8)
+
+    def forward(self, x):
+        if self.inverted_bottleneck is not None:
+            self.inverted_bottleneck.conv.active_out_channel = self.active_middle_channel(x.size(1))
+        self.depth_conv.conv.active_kernel_size = self.active_kernel_size
+        self.point_linear.conv.active_out_channel = self.active_out_channel
+        if self.inverted_bottleneck is not None:
+            x = self.inverted_bottleneck(x)
+        return self.point_linear(self.depth_conv(x))
+
+    @property
+    def module_str(self):
+        return "(O%d, E%.1f, K%d)" % (self.active_out_channel, self.active_expand_ratio, self.active_kernel_size)
+
+    @property
+    def config(self):
+        return {
+            "name": DynamicMBConvLayer.__name__, "in_channel_list": self.in_channel_list,
+            "out_channel_list": self.out_channel_list, "kernel_size_list": self.kernel_size_list,
+            "expand_ratio_list": self.expand_ratio_list, "stride": self.stride, "act_func": self.act_func,
+            "use_se": self.use_se,
+        }
+
+    @staticmethod
+    def build_from_config(config):
+        return DynamicMBConvLayer(**config)
+
+    # ------------------------------------------------------------------ sub-network extraction
+    def get_active_subnet(self, in_channel, preserve_weight=True):
+        """a static MBInvertedConvLayer holding the active slice of every weight (reference :112-154)."""
+        mid = self.active_middle_channel(in_channel)
+        sub = MBInvertedConvLayer(in_channel, self.active_out_channel, self.active_kernel_size, self.stride,
+                                  self.active_expand_ratio, act_func=self.act_func, mid_channels=mid,
+                                  use_se=self.use_se).to(get_net_device(self))
+        if not preserve_weight:
+            return sub
+        with torch.no_grad():
+            if sub.inverted_bottleneck is not None:
+                sub.inverted_bottleneck.conv.weight.copy_(
+                    self.inverted_bottleneck.conv.conv.weight[:mid, :in_channel])
+                copy_bn(sub.inverted_bottleneck.bn, self.inverted_bottleneck.bn.bn)
+            sub.depth_conv.conv.weight.copy_(self.depth_conv.conv.get_active_filter(mid, self.active_kernel_size))
+            copy_bn(sub.depth_conv.bn, self.depth_conv.bn.bn)
+            sub.point_linear.conv.weight.copy_(self.point_linear.conv.conv.weight[:self.active_out_channel, :mid])
+            copy_bn(sub.point_linear.bn, self.point_linear.bn.bn)
+        return sub
+
+    def re_organize_middle_weights(self, expand_ratio_stage=0):
+        """sort the middle channels by the L1 importance of the project weights so that narrower
+        expand ratios keep the most important channels (reference :156-199)."""
+        w_proj = self.point_linear.conv.conv.weight.data
+        importance = torch.sum(torch.abs(w_proj), dim=(0, 2, 3))
+        if expand_ratio_stage > 0:
+            widths = sorted(copy.deepcopy(self.expand_ratio_list), reverse=True)
+            keep = round(max(self.in_channel_list) * widths[expand_ratio_stage])
+            # channels beyond the already-shrunk width keep their order, below everything else
+            importance[keep:] = torch.arange(0, keep - importance.size(0), -1, device=importance.device,
+                                             dtype=importance.dtype)
+        _, order = torch.sort(importance, dim=0, descending=True)
+        self.point_linear.conv.conv.weight.data = torch.index_select(w_proj, 1, order)
+        adjust_bn_according_to_idx(self.depth_conv.bn.bn, order)
+        self.depth_conv.conv.conv.weight.data = torch.index_select(self.depth_conv.conv.conv.weight.data, 0, order)
+        if self.inverted_bottleneck is None:
+            return order
+        adjust_bn_according_to_idx(self.inverted_bottleneck.bn.bn, order)
+        self.inverted_bottleneck.conv.conv.weight.data = torch.index_select(
+            self.inverted_bottleneck.conv.conv.weight.data, 0, order)
+        return None

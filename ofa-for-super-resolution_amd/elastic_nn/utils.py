@@ -1,0 +1,75 @@
+"""BN helpers used by DynamicMBConvLayer.get_active_subnet / re_organize_middle_weights
+(reference ofa/elastic_nn/utils.py:67-82) and BN re-calibration for sampled sub-networks (:16-64)."""
+import copy
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def adjust_bn_according_to_idx(bn, idx):
+    """permute a BatchNorm's channels (reference :67-71)"""
+    bn.weight.data = torch.index_select(bn.weight.data, 0, idx)
+    bn.bias.data = torch.index_select(bn.bias.data, 0, idx)
+    bn.running_mean.data = torch.index_select(bn.running_mean.data, 0, idx)
+    bn.running_var.data = torch.index_select(bn.running_var.data, 0, idx)
+
+
+def copy_bn(target_bn, src_bn):
+    """copy the first target.num_features channels (reference :74-82)"""
+    n = target_bn.num_features
+    target_bn.weight.data.copy_(src_bn.weight.data[:n])
+    target_bn.bias.data.copy_(src_bn.bias.data[:n])
+    target_bn.running_mean.data.copy_(src_bn.running_mean.data[:n])
+    target_bn.running_var.data.copy_(src_bn.running_var.data[:n])
+
+
+def set_running_statistics(model, data_loader, input_key="2x_down_image", device=None):
+    """Re-estimate BN running statistics of the ACTIVE sub-network (reference :16-64): every
+    BatchNorm2d temporarily records the batch mean / variance it sees over `data_loader`, and
+    the averages (over batches) of the first `feature_dim` channels replace the running
+    statistics.  The reference feeds classification batches `(images, labels)`; the SR loaders
+    yield dicts, `input_key` picks the LR tensor."""
+    from .modules.dynamic_op import DynamicBatchNorm2d
+
+    stats = {}
+    forward_model = copy.deepcopy(model)
+    device = device or next(model.parameters()).device
+
+    def hook(bn, name):
+        stats[name] = {"mean_sum": None, "var_sum": None, "n": 0}
+
+        def fwd(x):
+            mean = x.mean(dim=(0, 2, 3), keepdim=True)
+            var = ((x - mean) ** 2).mean(dim=(0, 2, 3), keepdim=True)
+            rec = stats[name]
+            m, v = mean.detach().flatten().float(), var.detach().flatten().float()
+            rec["mean_sum"] = m if rec["mean_sum"] is None else rec["mean_sum"] + m
+            rec["var_sum"] = v if rec["var_sum"] is None else rec["var_sum"] + v
+            rec["n"] += 1
+            c = mean.size(1)
+            return F.batch_norm(x, mean.flatten(), var.flatten(), bn.weight[:c], bn.bias[:c], False, 0.0, bn.eps)
+
+        return fwd
+
+    for name, m in forward_model.named_modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.forward = hook(m, name)
+
+    flag = DynamicBatchNorm2d.SET_RUNNING_STATISTICS
+    DynamicBatchNorm2d.SET_RUNNING_STATISTICS = True
+    try:
+        with torch.no_grad():
+            for batch in data_loader:
+                x = batch[input_key] if isinstance(batch, dict) else batch[0]
+                forward_model(x.to(device))
+    finally:
+        DynamicBatchNorm2d.SET_RUNNING_STATISTICS = flag
+
+    for name, m in model.named_modules():
+        rec = stats.get(name)
+        if rec is None or rec["n"] == 0 or not isinstance(m, nn.BatchNorm2d):
+            continue
+        c = rec["mean_sum"].numel()
+        m.running_mean.data[:c].copy_(rec["mean_sum"] / rec["n"])
+        m.running_var.data[:c].copy_(rec["var_sum"] / rec["n"])

@@ -46,6 +46,46 @@ def _ws(nbytes, device):
     return t, ctypes.c_void_p(t.data_ptr()), ctypes.c_size_t(n)
 
 
+class KernelTimer(object):
+    """optional per-launch timing of the HIP-library kernels with events recorded on the stream the
+    kernels are launched on (torch's current stream).  Used by bench.py for the `roofline` object:
+    it stores (elapsed, algorithmic bytes, flops) per kernel name.  Off by default (TIMER is None)."""
+
+    def __init__(self):
+        self.records = {}   # name -> list of (start_event, end_event, bytes, flops)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _, _ in recs]
+            out[name] = {"launches": len(recs), "total_ms": float(sum(ms)), "avg_us": 1e3 * float(sum(ms)) / len(recs),
+                         "bytes": float(sum(r[2] for r in recs)), "flops": float(sum(r[3] for r in recs))}
+        return out
+
+
+TIMER = None
+
+
+class _timed(object):
+    __slots__ = ("name", "nbytes", "flops", "start")
+
+    def __init__(self, name, nbytes=0, flops=0):
+        self.name, self.nbytes, self.flops = name, nbytes, flops
+
+    def __enter__(self):
+        if TIMER is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+
+    def __exit__(self, *exc):
+        if TIMER is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            TIMER.records.setdefault(self.name, []).append((self.start, end, self.nbytes, self.flops))
+        return False
+
+
 def _f32_param(w):
     if w.dtype != torch.float32:
         raise _C.OfasrError("weights / filters are fp32 master copies (got %s)" % w.dtype)
@@ -69,8 +109,9 @@ def _shuffle_raw(x, r, inverse):
         C, H, W = Cx // (r * r), Hx, Wx
         y = torch.empty((N, C, H * r, W * r), dtype=x.dtype, device=x.device)
         fn = _C.lib().ofasr_pixel_shuffle
-    _C.check(fn(_p(x), _p(y), N, C, H, W, r, x.element_size(), _stream()),
-             "pixel_unshuffle" if inverse else "pixel_shuffle")
+    with _timed("pixel_unshuffle" if inverse else "pixel_shuffle", 2 * x.numel() * x.element_size()):
+        _C.check(fn(_p(x), _p(y), N, C, H, W, r, x.element_size(), _stream()),
+                 "pixel_unshuffle" if inverse else "pixel_shuffle")
     return y
 
 
@@ -134,8 +175,9 @@ class KTransformFn(Function):
         K = chain[-1]
         f = torch.empty((C, 1, K, K), dtype=torch.float32, device=w.device)
         ks, n, arr = _kt_args(chain, mats)
-        _C.check(_C.lib().ofasr_ktransform_fwd(_p(w), ks, n, arr, 1 if transform else 0, _p(f), C, _stream()),
-                 "ktransform_fwd")
+        with _timed("ktransform_fwd", 4 * (C * chain[0] ** 2 + C * K * K + sum(m.numel() for m in mats))):
+            _C.check(_C.lib().ofasr_ktransform_fwd(_p(w), ks, n, arr, 1 if transform else 0, _p(f), C, _stream()),
+                     "ktransform_fwd")
         ctx.save_for_backward(w, *mats)
         ctx.meta = (C, tuple(chain), bool(transform))
         return f
@@ -152,8 +194,9 @@ class KTransformFn(Function):
         darr = (ctypes.c_void_p * max(n, 1))(*([d.data_ptr() for d in dmats] if dmats else [None] * max(n, 1)))
         need = _C.lib().ofasr_ktransform_bwd_workspace(ks, n, C) if (transform and mats) else 0
         wst, wsp, wsn = _ws(need, w.device)
-        _C.check(_C.lib().ofasr_ktransform_bwd(_p(w), ks, n, arr, 1 if transform else 0, _p(df), _p(dw), darr, C,
-                                               wsp, wsn, _stream()), "ktransform_bwd")
+        with _timed("ktransform_bwd", 4 * (2 * C * chain[0] ** 2 + C * chain[-1] ** 2 + 2 * sum(m.numel() for m in mats))):
+            _C.check(_C.lib().ofasr_ktransform_bwd(_p(w), ks, n, arr, 1 if transform else 0, _p(df), _p(dw), darr, C,
+                                                   wsp, wsn, _stream()), "ktransform_bwd")
         return (dw, None, None, None) + tuple(dmats)
 
 
@@ -171,7 +214,8 @@ class DWConvFn(Function):
         if f.shape[0] != C:
             raise _C.OfasrError("dwconv: filter has %d channels, input has %d" % (f.shape[0], C))
         y = torch.empty_like(x)
-        _C.check(_C.lib().ofasr_dwconv_fwd(_p(x), _p(f), _p(y), N, C, H, W, K, _dt(x), _stream()), "dwconv_fwd")
+        with _timed("dwconv_fwd_k%d" % K, 2 * x.numel() * x.element_size() + 4 * f.numel(), 2 * K * K * x.numel()):
+            _C.check(_C.lib().ofasr_dwconv_fwd(_p(x), _p(f), _p(y), N, C, H, W, K, _dt(x), _stream()), "dwconv_fwd")
         ctx.save_for_backward(x, f)
         return y
 
@@ -186,12 +230,14 @@ class DWConvFn(Function):
         dx = df = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _C.check(L.ofasr_dwconv_dgrad(_p(dy), _p(f), _p(dx), N, C, H, W, K, _dt(x), _stream()), "dwconv_dgrad")
+            with _timed("dwconv_dgrad_k%d" % K, 2 * x.numel() * x.element_size() + 4 * f.numel(), 2 * K * K * x.numel()):
+                _C.check(L.ofasr_dwconv_dgrad(_p(dy), _p(f), _p(dx), N, C, H, W, K, _dt(x), _stream()), "dwconv_dgrad")
         if ctx.needs_input_grad[1]:
             df = torch.empty_like(f)
             wst, wsp, wsn = _ws(L.ofasr_dwconv_wgrad_workspace(N, C, H, W, K), x.device)
-            _C.check(L.ofasr_dwconv_wgrad(_p(dy), _p(x), _p(df), N, C, H, W, K, _dt(x), wsp, wsn, _stream()),
-                     "dwconv_wgrad")
+            with _timed("dwconv_wgrad_k%d" % K, 2 * x.numel() * x.element_size() + 4 * f.numel(), 2 * K * K * x.numel()):
+                _C.check(L.ofasr_dwconv_wgrad(_p(dy), _p(x), _p(df), N, C, H, W, K, _dt(x), wsp, wsn, _stream()),
+                         "dwconv_wgrad")
         return dx, df
 
 
@@ -217,8 +263,10 @@ class PWConvFn(Function):
         if Cin > ldw or cout > w.shape[0]:
             raise _C.OfasrError("pwconv: slice [%d,%d] exceeds weight %s" % (cout, Cin, tuple(w.shape)))
         y = torch.empty((N, cout, H, W), dtype=x.dtype, device=x.device)
-        _C.check(_C.lib().ofasr_pwconv_fwd(_p(x), _p(w), ldw, _p(y), N, Cin, cout, H * W, _dt(x), _stream()),
-                 "pwconv_fwd")
+        with _timed("pwconv_fwd_%dto%d" % (Cin, cout), (x.numel() + y.numel()) * x.element_size() + 4 * Cin * cout,
+                    2 * Cin * cout * N * H * W):
+            _C.check(_C.lib().ofasr_pwconv_fwd(_p(x), _p(w), ldw, _p(y), N, Cin, cout, H * W, _dt(x), _stream()),
+                     "pwconv_fwd")
         ctx.save_for_backward(x, w)
         ctx.cout = cout
         return y
@@ -234,13 +282,17 @@ class PWConvFn(Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _C.check(L.ofasr_pwconv_dgrad(_p(dy), _p(w), ldw, _p(dx), N, Cin, cout, H * W, _dt(x), _stream()),
-                     "pwconv_dgrad")
+            with _timed("pwconv_dgrad_%dto%d" % (cout, Cin), (x.numel() + dy.numel()) * x.element_size() + 4 * Cin * cout,
+                        2 * Cin * cout * N * H * W):
+                _C.check(L.ofasr_pwconv_dgrad(_p(dy), _p(w), ldw, _p(dx), N, Cin, cout, H * W, _dt(x), _stream()),
+                         "pwconv_dgrad")
         if ctx.needs_input_grad[1]:
             dw = torch.zeros_like(w)
             wst, wsp, wsn = _ws(L.ofasr_pwconv_wgrad_workspace(N, Cin, cout, H * W), x.device)
-            _C.check(L.ofasr_pwconv_wgrad(_p(dy), _p(x), _p(dw), ldw, N, Cin, cout, H * W, _dt(x), wsp, wsn,
-                                          _stream()), "pwconv_wgrad")
+            with _timed("pwconv_wgrad_%dx%d" % (cout, Cin), (x.numel() + dy.numel()) * x.element_size() + 4 * Cin * cout,
+                        2 * Cin * cout * N * H * W):
+                _C.check(L.ofasr_pwconv_wgrad(_p(dy), _p(x), _p(dw), ldw, N, Cin, cout, H * W, _dt(x), wsp, wsn,
+                                              _stream()), "pwconv_wgrad")
         return dx, dw, None
 
 
