@@ -189,7 +189,11 @@ def run_cpu_baseline(args, S):
     import torch.nn.functional as F
     from oracle import s4_port
 
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))   # a 1-GPU box grants this job a 16-core share (more threads only thrash)
     torch.set_num_threads(cores)
     sd = s4_port.he_fout_state_dict(seed=0)
     params = []

