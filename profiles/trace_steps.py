@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Aggregate a rocprofv3 kernel-trace CSV over the last N training steps (steps are delimited by the
+optimizer's multi_tensor_apply launches).  usage: tools_trace_steps.py <kernel_trace.csv> [nsteps] [top]"""
+import collections
+import csv
+import sys
+
+
+def main():
+    path = sys.argv[1]
+    nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+    rows = list(csv.DictReader(open(path)))
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
+    names = [e[2] for e in ev]
+    opt = [i for i, n in enumerate(names) if "multi_tensor_apply" in n]
+    ends = [i for j, i in enumerate(opt) if j == len(opt) - 1 or opt[j + 1] - i > 50]
+    lo, hi = ends[-(nsteps + 1)] + 1, ends[-1] + 1
+    sel = ev[lo:hi]
+    span = (sel[-1][1] - sel[0][0]) / 1e6
+    agg = collections.defaultdict(lambda: [0, 0])
+    for s, e, n in sel:
+        agg[n][0] += e - s
+        agg[n][1] += 1
+    busy = sum(v[0] for v in agg.values()) / 1e6
+    print("steps=%d  wall/step=%.3f ms  gpu-busy/step=%.3f ms  kernels/step=%.0f" % (
+        nsteps, span / nsteps, busy / nsteps, len(sel) / nsteps))
+    for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
+        print("%-96s n/step=%6.1f ms/step=%7.3f avg_us=%8.1f" % (n[:96], c / nsteps, t / 1e6 / nsteps, t / 1e3 / c))
+
+
+if __name__ == "__main__":
+    main()
