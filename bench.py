@@ -73,6 +73,7 @@ def main():
 
     torch.manual_seed(0)
     random.seed(0)
+    torch.backends.cudnn.benchmark = True                           # sr_run_manager.py:153 (MIOpen find mode)
     dop.DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = 1            # train_ofa_net_sr_simple.py:183
     net = nets.OFAMobileNetS4(ks_list=[3, 5, 7], expand_ratio_list=[6], depth_list=[4], pixelshuffle_depth_list=[2])
     net.init_model("he_fout")

@@ -78,13 +78,23 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_strip_kernel(const T* __rest
 
     const int hstart = h0 - PAD;
     const int niter = (h1 - h0) + 2 * PAD;
+    // K input rows are fetched per batch, one batch ahead of the arithmetic (2K independent loads in flight
+    // per wave): the kernel is latency-bound otherwise (one 128/256-byte row per load).
+    auto load_row = [&](int t) -> float {
+        const int hin = hstart + t;
+        return (t < niter && hin >= 0 && hin < H && in_col) ? to_float(xp[(long long)hin * W]) : 0.f;
+    };
+    float xin[K], xnext[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) xin[u] = load_row(u);
     for (int base = 0; base < niter; base += K) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) xnext[u] = load_row(base + K + u);
 #pragma unroll
         for (int u = 0; u < K; ++u) {
             const int t = base + u;
             const int hin = hstart + t;
-            float v = 0.f;
-            if (t < niter && hin >= 0 && hin < H && in_col) v = to_float(xp[(long long)hin * W]);
+            const float v = xin[u];
             float s[K];
 #pragma unroll
             for (int j = 0; j < K; ++j) {
@@ -112,6 +122,8 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_strip_kernel(const T* __rest
                 yp[(long long)hout * W] = from_float<T>(acc[(u + 1) % K]);
             acc[(u + 1) % K] = 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < K; ++u) xin[u] = xnext[u];
     }
 }
 
@@ -149,14 +161,27 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_wgrad_kernel(const T* __rest
                 xr[m] = (own && r >= 0 && r < H) ? to_float(xp[(long long)r * W]) : 0.f;
             }
             xr[K - 1] = 0.f;
+            auto load_x = [&](int h) -> float {   // the new ring row needed at iteration h
+                const int rnew = h + PAD;
+                return (own && h < H && rnew < H) ? to_float(xp[(long long)rnew * W]) : 0.f;
+            };
+            auto load_g = [&](int h) -> float { return (h < H && in_col) ? to_float(dp[(long long)h * W]) : 0.f; };
+            float xb[K], gb[K], xn_[K], gn_[K];
+#pragma unroll
+            for (int u = 0; u < K; ++u) {
+                xb[u] = load_x(u);
+                gb[u] = load_g(u);
+            }
             for (int base = 0; base < H; base += K) {
 #pragma unroll
+                for (int u = 0; u < K; ++u) {   // next batch in flight while this one is consumed
+                    xn_[u] = load_x(base + K + u);
+                    gn_[u] = load_g(base + K + u);
+                }
+#pragma unroll
                 for (int u = 0; u < K; ++u) {
-                    const int h = base + u;
-                    const int rnew = h + PAD;
-                    xr[(u + K - 1) % K] =
-                        (own && h < H && rnew < H) ? to_float(xp[(long long)rnew * W]) : 0.f;
-                    const float g = (h < H && in_col) ? to_float(dp[(long long)h * W]) : 0.f;
+                    xr[(u + K - 1) % K] = xb[u];
+                    const float g = gb[u];
                     float gs[K];  // gs[j](lane) = dy(lane - j + PAD)
 #pragma unroll
                     for (int j = 0; j < K; ++j) {
@@ -176,6 +201,11 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_wgrad_kernel(const T* __rest
 #pragma unroll
                         for (int j = 0; j < K; ++j) acc[i * K + j] = fmaf(gs[j], xv, acc[i * K + j]);
                     }
+                }
+#pragma unroll
+                for (int u = 0; u < K; ++u) {
+                    xb[u] = xn_[u];
+                    gb[u] = gn_[u];
                 }
             }
         }
@@ -200,7 +230,7 @@ __global__ void __launch_bounds__(256) dw_wgrad_reduce_kernel(const float* __res
 
 static int wgrad_parts(int64_t N, int64_t C) {
     // enough waves to fill 256 CUs x ~8 waves, at most one part per image
-    int64_t want = cdiv(2048, C > 0 ? C : 1);
+    int64_t want = cdiv(6144, C > 0 ? C : 1);
     if (want < 1) want = 1;
     if (want > N) want = N;
     return (int)want;

@@ -23,9 +23,8 @@
 // tile whose pixel positions are permuted at staging time, read with ds_read_b64_tr_b16.
 //
 // Two schedules cover the shapes of the MB block (and, slower, any other shape):
-//   fan-out (K <= 64, any M)  expand fwd / project dgrad: the 64-channel X tile is staged once,
-//                             the weight slice lives in LDS for the life of a persistent block,
-//                             waves walk the output-channel blocks.
+//   fan-out (K <= 64, any M)  expand fwd / project dgrad: one block = 128 pixels x 128 output rows; the
+//                             64-channel X tile and the 128-row weight slab are staged once.
 //   fan-in  (any K, M <= 64 per pass) project fwd / expand dgrad: K is walked in 64-channel chunks
 //                             with the accumulators resident.
 #include "ofasr_common.h"
@@ -45,7 +44,6 @@ constexpr int XROW16 = 320;             // bytes per channel row of a 16-bit X t
 constexpr int XROW32 = 512;             // bytes per channel row of an fp32 X tile
 constexpr int WROW16 = 128;             // bytes per 64-k row of a 16-bit operand tile
 constexpr int WROW32 = 256;             // bytes per 64-k row of an fp32 operand tile
-constexpr size_t PW_MAX_W_LDS = 98304;  // 96 KiB of weights resident in LDS
 
 template <typename T> struct Mma16;
 template <> struct Mma16<bf16_t> {
@@ -90,23 +88,85 @@ __device__ __forceinline__ void lds_store_w(char* base, int off, float v) {
     else *reinterpret_cast<float*>(base + off) = v;
 }
 
-// stage W rows [m0, m0+rows) x k in [k0, k0+64) (zero outside the slice) into one operand tile
-template <typename T>
-__device__ __forceinline__ void stage_w_tile(char* Wt, const WView& wv, int m0, int rows, int k0) {
+// stage W rows [m0, m0+ROWS) x k in [k0, k0+64) (zero outside the slice) into one operand tile.
+// Vector form: every thread issues all of its 16-byte global loads first (ROWS/16 independent loads in
+// flight), then converts and writes LDS -- the slice is L2-resident, so this is latency-, not
+// bandwidth-limited and the loads must overlap.  Needs w 16-byte aligned and ldw % 4 == 0 (WVEC).
+template <typename T, int ROWS, bool WVEC>
+__device__ __forceinline__ void stage_w_tile(char* Wt, const WView& wv, int m0, int k0) {
     const int tid = threadIdx.x;
-    if (wv.sk == 1) {
-        for (int e = tid; e < rows * 64; e += PW_THREADS) {
-            const int r = e >> 6, k = e & 63;
-            const int m = m0 + r, kk = k0 + k;
-            const float v = (m < wv.M && kk < wv.K) ? wv.w[(long long)m * wv.sm + kk] : 0.f;
-            lds_store_w<T>(Wt, wtile_off<T>(r, k), v);
+    if constexpr (!WVEC) {
+        if (wv.sk == 1) {
+            for (int e = tid; e < ROWS * 64; e += PW_THREADS) {
+                const int r = e >> 6, k = e & 63;
+                const int m = m0 + r, kk = k0 + k;
+                const float v = (m < wv.M && kk < wv.K) ? wv.w[(long long)m * wv.sm + kk] : 0.f;
+                lds_store_w<T>(Wt, wtile_off<T>(r, k), v);
+            }
+        } else {
+            for (int e = tid; e < ROWS * 64; e += PW_THREADS) {
+                const int k = e / ROWS, r = e - k * ROWS;
+                const int m = m0 + r, kk = k0 + k;
+                const float v = (m < wv.M && kk < wv.K) ? wv.w[(long long)m * wv.sm + (long long)kk * wv.sk] : 0.f;
+                lds_store_w<T>(Wt, wtile_off<T>(r, k), v);
+            }
         }
-    } else {  // transposed view: consecutive threads walk m (the unit-stride direction)
-        for (int e = tid; e < rows * 64; e += PW_THREADS) {
-            const int k = e / rows, r = e - k * rows;
-            const int m = m0 + r, kk = k0 + k;
-            const float v = (m < wv.M && kk < wv.K) ? wv.w[(long long)m * wv.sm + (long long)kk * wv.sk] : 0.f;
-            lds_store_w<T>(Wt, wtile_off<T>(r, k), v);
+    } else {
+        constexpr int NIT = ROWS * 16 / PW_THREADS;  // float4 chunks per thread
+        float4 v[NIT];
+        if (wv.sk == 1) {  // row-major slice: chunk = 4 consecutive k of one row
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int q = tid + it * PW_THREADS;
+                const int r = q >> 4, k = 4 * (q & 15);
+                const int m = m0 + r, kk = k0 + k;
+                v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < wv.M) {
+                    const float* src = wv.w + (long long)m * wv.sm + kk;
+                    if (kk + 3 < wv.K) v[it] = *reinterpret_cast<const float4*>(src);
+                    else {
+                        if (kk < wv.K) v[it].x = src[0];
+                        if (kk + 1 < wv.K) v[it].y = src[1];
+                        if (kk + 2 < wv.K) v[it].z = src[2];
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int q = tid + it * PW_THREADS;
+                const int r = q >> 4, k = 4 * (q & 15);
+                if constexpr (Elem<T>::is16)
+                    *reinterpret_cast<uint2*>(Wt + wtile_off<T>(r, k)) =
+                        make_uint2(pack2<T>(v[it].x, v[it].y), pack2<T>(v[it].z, v[it].w));
+                else
+                    *reinterpret_cast<float4*>(Wt + wtile_off<T>(r, k)) = v[it];
+            }
+        } else {  // transposed view (dgrad): chunk = 4 consecutive rows m of one k
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int q = tid + it * PW_THREADS;
+                const int k = q / (ROWS / 4), r = 4 * (q - k * (ROWS / 4));
+                const int m = m0 + r, kk = k0 + k;
+                v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kk < wv.K) {
+                    const float* src = wv.w + (long long)kk * wv.sk + m;
+                    if (m + 3 < wv.M) v[it] = *reinterpret_cast<const float4*>(src);
+                    else {
+                        if (m < wv.M) v[it].x = src[0];
+                        if (m + 1 < wv.M) v[it].y = src[1];
+                        if (m + 2 < wv.M) v[it].z = src[2];
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int q = tid + it * PW_THREADS;
+                const int k = q / (ROWS / 4), r = 4 * (q - k * (ROWS / 4));
+                lds_store_w<T>(Wt, wtile_off<T>(r, k), v[it].x);
+                lds_store_w<T>(Wt, wtile_off<T>(r + 1, k), v[it].y);
+                lds_store_w<T>(Wt, wtile_off<T>(r + 2, k), v[it].z);
+                lds_store_w<T>(Wt, wtile_off<T>(r + 3, k), v[it].w);
+            }
         }
     }
 }
@@ -226,156 +286,131 @@ __device__ __forceinline__ void store_px(T* __restrict__ dst, int px, int HW, co
 }
 
 // ------------------------------------------------------------------------------------ fan-out
-// K <= 64.  grid.x persistent over pixel tiles, grid.y over M super-blocks of `mrows` rows.
-template <typename T, bool ALIGNED>
+// K <= 64.  One block = one 128-pixel tile x one 128-row slab of outputs (grid.y); wave w owns output
+// row block w of the slab: A (weights) from the swizzled LDS operand tile, B (pixels) by transposing
+// reads of the X tile, 16 MFMAs, packed 8/16-byte stores.  ~36 KB LDS and ~100 VGPRs per block keep
+// 4 blocks (16 waves) per CU so loads of one block overlap the MFMA/store phase of the others.
+constexpr int FO_ROWS = 128;
+template <typename T, bool ALIGNED, bool WVEC>
 __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y,
-                                                               int HW, int tiles_per_img, int total_tiles, int mrows) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int m_base = blockIdx.y * mrows;
-    const int mloc = min(mrows, wv.M - m_base);
-    const int ncb = (mloc + 31) >> 5;
-    char* Ws = smem;
-    char* Xs = smem + ncb * 32 * Elem<T>::wrow;
+                                                               int HW, int tiles_per_img) {
+    __shared__ __attribute__((aligned(16))) char Ws[FO_ROWS * Elem<T>::wrow];
+    __shared__ __attribute__((aligned(16))) char Xs[64 * Elem<T>::xrow];
+    const int m_base = blockIdx.y * FO_ROWS;
+    const int mloc = min(FO_ROWS, wv.M - m_base);
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int c = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x;
+    const int n = tile / tiles_per_img;
+    const int p0 = (tile - n * tiles_per_img) * PW_TILE;
+    const T* xn = x + (long long)n * wv.K * HW;
+    T* yn = y + ((long long)n * wv.M + m_base) * HW;
 
-    stage_w_tile<T>(Ws, wv, m_base, ncb * 32, 0);
+    stage_x_tile<T, 4, ALIGNED>(Xs, xn, wv.K, HW, 0, p0);
+    stage_w_tile<T, FO_ROWS, WVEC>(Ws, wv, m_base, 0);
+    __syncthreads();
 
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        const int n = tile / tiles_per_img;
-        const int p0 = (tile - n * tiles_per_img) * PW_TILE;
-        const T* xn = x + (long long)n * wv.K * HW;
-        T* yn = y + ((long long)n * wv.M + m_base) * HW;
-        __syncthreads();  // readers of the previous X tile are done (first pass: W tile written)
-        stage_x_tile<T, 4, ALIGNED>(Xs, xn, wv.K, HW, 0, p0);
-        __syncthreads();
-
-        if constexpr (Elem<T>::is16) {
-            s16x8 bf[4][4];
+    const int cb = wave;
+    if (32 * cb >= mloc) return;
+    const int row = 32 * cb + c;
+    f32x16 acc[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t) acc[t] = zero16();
+    if constexpr (Elem<T>::is16) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) bf[t][s] = read_b_frag16(Xs, 32 * t, s, lane);
-            for (int cb = wave; cb < ncb; cb += 4) {
-                const int row = 32 * cb + c;
-                s16x8 af[4];
+        for (int s = 0; s < 4; ++s) {
+            if (16 * s < wv.K) {
+                const s16x8 af = *reinterpret_cast<const s16x8*>(Ws + wtile_chunk_off<T>(row, 2 * s + h));
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    af[s] = *reinterpret_cast<const s16x8*>(Ws + wtile_chunk_off<T>(row, 2 * s + h));
-                f32x16 acc[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = zero16();
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = Mma16<T>::run(af[s], bf[t][s], acc[t]);
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int r = 32 * cb + acc_row(reg, h);
-                    if (r < mloc) {
-                        const float v[4] = {acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]};
-                        store_px<T, 4, ALIGNED>(yn + (long long)r * HW, p0 + 4 * c, HW, v);
-                    }
-                }
+                for (int t = 0; t < 4; ++t) acc[t] = Mma16<T>::run(af, read_b_frag16(Xs, 32 * t, s, lane), acc[t]);
             }
-        } else {
-            for (int cb = wave; cb < ncb; cb += 4) {
-                const int row = 32 * cb + c;
-                f32x16 acc[4];
+        }
+    } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = zero16();
+        for (int s4 = 0; s4 < 8; ++s4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(Ws + wtile_chunk_off<T>(row, 8 * h + s4));
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-                for (int s4 = 0; s4 < 8; ++s4) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(Ws + wtile_chunk_off<T>(row, 8 * h + s4));
-                    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                    for (int ss = 0; ss < 4; ++ss) {
-                        const int k = 32 * h + 4 * s4 + ss;  // MFMA k-slot h of step s <-> channel 32h + s
-                        const float4 b4 = *reinterpret_cast<const float4*>(Xs + k * XROW32 + c * 16);
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b4.x, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b4.y, acc[1], 0, 0, 0);
-                        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b4.z, acc[2], 0, 0, 0);
-                        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b4.w, acc[3], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int r = 32 * cb + acc_row(reg, h);
-                    if (r < mloc) {
-                        const float v[4] = {acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]};
-                        store_px<T, 4, ALIGNED>(yn + (long long)r * HW, p0 + 4 * c, HW, v);
-                    }
-                }
+            for (int ss = 0; ss < 4; ++ss) {
+                const int k = 32 * h + 4 * s4 + ss;  // MFMA k-slot h of step s <-> channel 32h + s
+                const float4 b4 = *reinterpret_cast<const float4*>(Xs + k * XROW32 + c * 16);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b4.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b4.y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b4.z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b4.w, acc[3], 0, 0, 0);
             }
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int r = 32 * cb + acc_row(reg, h);
+        if (r < mloc) {
+            const float v[4] = {acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]};
+            store_px<T, 4, ALIGNED>(yn + (long long)r * HW, p0 + 4 * c, HW, v);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------- fan-in
-// any K (<= kchunks*64 resident in LDS), 64 output rows per grid.y pass.
+// any K, 64 output rows per grid.y pass.  K is walked in 64-channel chunks: each chunk stages its X
+// tile (HBM) and its [64 x 64] weight chunk (L2) and adds into accumulators that stay in registers.
 // wave w: output row block cb = w&1, pixel half hh = w>>1 (64 pixels, 2 per lane).
-template <typename T, bool ALIGNED>
+template <typename T, bool ALIGNED, bool WVEC>
 __global__ void __launch_bounds__(PW_THREADS) pw_fanin_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y,
-                                                              int HW, int tiles_per_img, int total_tiles, int kchunks) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+                                                              int HW, int tiles_per_img, int kchunks) {
+    __shared__ __attribute__((aligned(16))) char Ws[64 * Elem<T>::wrow];
+    __shared__ __attribute__((aligned(16))) char Xs[64 * Elem<T>::xrow];
     const int m_base = blockIdx.y * 64;
     const int mloc = min(64, wv.M - m_base);
-    constexpr int WT = 64 * Elem<T>::wrow;  // bytes of one [64][64] operand tile
-    char* Ws = smem;
-    char* Xs = smem + (size_t)kchunks * WT;
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int c = lane & 31, h = lane >> 5;
     const int cb = wave & 1, hh = wave >> 1;
-
-    for (int kc = 0; kc < kchunks; ++kc) stage_w_tile<T>(Ws + (size_t)kc * WT, wv, m_base, 64, kc * 64);
-
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        const int n = tile / tiles_per_img;
-        const int p0 = (tile - n * tiles_per_img) * PW_TILE;
-        const T* xn = x + (long long)n * wv.K * HW;
-        T* yn = y + ((long long)n * wv.M + m_base) * HW;
-        f32x16 acc[2];
-        acc[0] = zero16();
-        acc[1] = zero16();
-        const int row = 32 * cb + c;
-        for (int kc = 0; kc < kchunks; ++kc) {
-            __syncthreads();
-            stage_x_tile<T, 2, ALIGNED>(Xs, xn, wv.K, HW, kc * 64, p0);
-            __syncthreads();
-            const char* Wt = Ws + (size_t)kc * WT;
-            if constexpr (Elem<T>::is16) {
+    const int tile = blockIdx.x;
+    const int n = tile / tiles_per_img;
+    const int p0 = (tile - n * tiles_per_img) * PW_TILE;
+    const T* xn = x + (long long)n * wv.K * HW;
+    T* yn = y + ((long long)n * wv.M + m_base) * HW;
+    f32x16 acc[2];
+    acc[0] = zero16();
+    acc[1] = zero16();
+    const int row = 32 * cb + c;
+    for (int kc = 0; kc < kchunks; ++kc) {
+        if (kc) __syncthreads();
+        stage_x_tile<T, 2, ALIGNED>(Xs, xn, wv.K, HW, kc * 64, p0);
+        stage_w_tile<T, 64, WVEC>(Ws, wv, m_base, kc * 64);
+        __syncthreads();
+        if constexpr (Elem<T>::is16) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const s16x8 af = *reinterpret_cast<const s16x8*>(Wt + wtile_chunk_off<T>(row, 2 * s + h));
-                    const s16x8 b0 = read_b_frag16(Xs, 64 * hh, s, lane);
-                    const s16x8 b1 = read_b_frag16(Xs, 64 * hh + 32, s, lane);
-                    acc[0] = Mma16<T>::run(af, b0, acc[0]);
-                    acc[1] = Mma16<T>::run(af, b1, acc[1]);
-                }
-            } else {
+            for (int s = 0; s < 4; ++s) {
+                const s16x8 af = *reinterpret_cast<const s16x8*>(Ws + wtile_chunk_off<T>(row, 2 * s + h));
+                const s16x8 b0 = read_b_frag16(Xs, 64 * hh, s, lane);
+                const s16x8 b1 = read_b_frag16(Xs, 64 * hh + 32, s, lane);
+                acc[0] = Mma16<T>::run(af, b0, acc[0]);
+                acc[1] = Mma16<T>::run(af, b1, acc[1]);
+            }
+        } else {
 #pragma unroll
-                for (int s4 = 0; s4 < 8; ++s4) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(Wt + wtile_chunk_off<T>(row, 8 * h + s4));
-                    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+            for (int s4 = 0; s4 < 8; ++s4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(Ws + wtile_chunk_off<T>(row, 8 * h + s4));
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-                    for (int ss = 0; ss < 4; ++ss) {
-                        const int k = 32 * h + 4 * s4 + ss;
-                        const float2 b2 = *reinterpret_cast<const float2*>(Xs + k * XROW32 + (64 * hh + 2 * c) * 4);
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b2.x, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b2.y, acc[1], 0, 0, 0);
-                    }
+                for (int ss = 0; ss < 4; ++ss) {
+                    const int k = 32 * h + 4 * s4 + ss;
+                    const float2 b2 = *reinterpret_cast<const float2*>(Xs + k * XROW32 + (64 * hh + 2 * c) * 4);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b2.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b2.y, acc[1], 0, 0, 0);
                 }
             }
         }
+    }
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int r = 32 * cb + acc_row(reg, h);
-            if (r < mloc) {
-                const float v[2] = {acc[0][reg], acc[1][reg]};
-                store_px<T, 2, ALIGNED>(yn + (long long)r * HW, p0 + 64 * hh + 2 * c, HW, v);
-            }
+    for (int reg = 0; reg < 16; ++reg) {
+        const int r = 32 * cb + acc_row(reg, h);
+        if (r < mloc) {
+            const float v[2] = {acc[0][reg], acc[1][reg]};
+            store_px<T, 2, ALIGNED>(yn + (long long)r * HW, p0 + 64 * hh + 2 * c, HW, v);
         }
     }
 }
@@ -518,66 +553,39 @@ static WgradPlan wgrad_plan(int64_t N, int64_t Cin, int64_t Cout, int64_t HW) {
     return p;
 }
 
-template <typename F>
-static void allow_big_lds(F kernel) {
-    // one-time per kernel: let a block ask for more than the default dynamic-LDS limit (gfx950: 160 KiB/CU)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-}
-
 static bool aligned_for(const void* a, const void* b, int64_t HW, bool is16) {
     const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b);
     return (bits & 15) == 0 && (HW % (is16 ? 8 : 4)) == 0;
+}
+
+template <typename T, bool AL, bool WV>
+static void launch_gemm_v(const void* x, WView wv, void* y, int64_t HW, int tiles_per_img, int total_tiles,
+                          hipStream_t st) {
+    if (wv.K <= 64) {
+        dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, FO_ROWS));
+        hipLaunchKernelGGL((pw_fanout_kernel<T, AL, WV>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
+                           (int)HW, tiles_per_img);
+    } else {
+        dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, 64));
+        hipLaunchKernelGGL((pw_fanin_kernel<T, AL, WV>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
+                           (int)HW, tiles_per_img, (int)cdiv(wv.K, 64));
+    }
 }
 
 template <typename T>
 static int launch_gemm(const char* name, const void* x, WView wv, void* y, int64_t N, int64_t HW, hipStream_t st) {
     constexpr bool is16 = Elem<T>::is16;
     const bool al = aligned_for(x, y, HW, is16);
+    const long long ld = wv.sk == 1 ? wv.sm : wv.sk;
+    const bool wvec = (reinterpret_cast<uintptr_t>(wv.w) & 15) == 0 && (ld % 4) == 0;
     const int tiles_per_img = (int)cdiv(HW, PW_TILE);
     const int64_t total64 = N * tiles_per_img;
     OFASR_REQUIRE(total64 <= INT32_MAX, OFASR_ERR_UNSUPPORTED, "%s: too many pixel tiles", name);
     const int total_tiles = (int)total64;
-    const int xbytes = 64 * Elem<T>::xrow;
-    if (wv.K <= 64) {
-        // fan-out: M super-blocks so that the resident weight tile stays <= 96 KiB
-        const int max_rows = (int)(PW_MAX_W_LDS / Elem<T>::wrow);  // 768 (16-bit) / 384 (fp32)
-        const int mrows = wv.M <= max_rows ? ((wv.M + 31) / 32) * 32 : max_rows;
-        const int gy = (int)cdiv(wv.M, mrows);
-        const size_t lds = (size_t)mrows * Elem<T>::wrow + xbytes;
-        const int per_cu = lds <= 80 * 1024 ? 2 : 1;
-        int gx = 256 * per_cu / gy;
-        if (gx < 1) gx = 1;
-        if (gx > total_tiles) gx = total_tiles;
-        static const bool once_fo = (allow_big_lds(pw_fanout_kernel<T, true>), allow_big_lds(pw_fanout_kernel<T, false>), true);
-        (void)once_fo;
-        if (al)
-            hipLaunchKernelGGL((pw_fanout_kernel<T, true>), dim3(gx, gy), dim3(PW_THREADS), lds, st, (const T*)x, wv,
-                               (T*)y, (int)HW, tiles_per_img, total_tiles, mrows);
-        else
-            hipLaunchKernelGGL((pw_fanout_kernel<T, false>), dim3(gx, gy), dim3(PW_THREADS), lds, st, (const T*)x, wv,
-                               (T*)y, (int)HW, tiles_per_img, total_tiles, mrows);
-    } else {
-        const int kchunks = (int)cdiv(wv.K, 64);
-        const size_t wbytes = (size_t)kchunks * 64 * Elem<T>::wrow;
-        OFASR_REQUIRE(wbytes <= PW_MAX_W_LDS, OFASR_ERR_UNSUPPORTED,
-                      "%s: reduction width K=%d needs %zu B of LDS weights (> %zu)", name, wv.K, wbytes,
-                      (size_t)PW_MAX_W_LDS);
-        const int gy = (int)cdiv(wv.M, 64);
-        const size_t lds = wbytes + xbytes;
-        const int per_cu = lds <= 80 * 1024 ? 2 : 1;
-        int gx = 256 * per_cu / gy;
-        if (gx < 1) gx = 1;
-        if (gx > total_tiles) gx = total_tiles;
-        static const bool once_fi = (allow_big_lds(pw_fanin_kernel<T, true>), allow_big_lds(pw_fanin_kernel<T, false>), true);
-        (void)once_fi;
-        if (al)
-            hipLaunchKernelGGL((pw_fanin_kernel<T, true>), dim3(gx, gy), dim3(PW_THREADS), lds, st, (const T*)x, wv,
-                               (T*)y, (int)HW, tiles_per_img, total_tiles, kchunks);
-        else
-            hipLaunchKernelGGL((pw_fanin_kernel<T, false>), dim3(gx, gy), dim3(PW_THREADS), lds, st, (const T*)x, wv,
-                               (T*)y, (int)HW, tiles_per_img, total_tiles, kchunks);
-    }
+    if (al && wvec) launch_gemm_v<T, true, true>(x, wv, y, HW, tiles_per_img, total_tiles, st);
+    else if (al) launch_gemm_v<T, true, false>(x, wv, y, HW, tiles_per_img, total_tiles, st);
+    else if (wvec) launch_gemm_v<T, false, true>(x, wv, y, HW, tiles_per_img, total_tiles, st);
+    else launch_gemm_v<T, false, false>(x, wv, y, HW, tiles_per_img, total_tiles, st);
     return check_launch(name);
 }
 
