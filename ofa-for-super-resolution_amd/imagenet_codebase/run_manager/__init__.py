@@ -1,0 +1,53 @@
+"""Per-dataset run configs (mirror of reference ofa/imagenet_codebase/run_manager/__init__.py:127-232).
+`Div2K_SetXXRunConfig(**args.__dict__)` keeps working; its lazy `data_provider` resolves to the real
+DIV2K provider when the dataset directory exists and to the synthetic provider otherwise."""
+import os
+
+from .sr_run_manager import RunConfig, SRRunManager  # noqa: F401
+from ..data_providers.synthetic_sr import SyntheticSRDataProvider
+
+
+class SyntheticSRRunConfig(RunConfig):
+
+    def __init__(self, n_epochs=1, init_lr=1e-3, lr_schedule_type="cosine", lr_schedule_param=None,
+                 dataset="synthetic_sr", train_batch_size=16, test_batch_size=1, valid_size=None, opt_type="adam",
+                 opt_param=None, weight_decay=3e-5, label_smoothing=0.0, no_decay_keys="bn#bias", mixup_alpha=None,
+                 model_init="he_fout", validation_frequency=1, print_frequency=10, n_worker=0, image_size=256,
+                 n_train_batches=4, n_test_batches=2, data_seed=0, test_sizes=None, **kwargs):
+        super().__init__(n_epochs, init_lr, lr_schedule_type, lr_schedule_param, dataset, train_batch_size,
+                         test_batch_size, valid_size, opt_type, opt_param, weight_decay, label_smoothing,
+                         no_decay_keys, mixup_alpha, model_init, validation_frequency, print_frequency)
+        self.n_worker = n_worker
+        self.image_size = image_size
+        self._synthetic = dict(n_train_batches=n_train_batches, n_test_batches=n_test_batches, seed=data_seed,
+                               test_sizes=test_sizes)
+
+    @property
+    def data_provider(self):
+        if self.__dict__.get("_data_provider", None) is None:
+            from ... import distributed as dd
+            self.__dict__["_data_provider"] = SyntheticSRDataProvider(
+                train_batch_size=self.train_batch_size, test_batch_size=self.test_batch_size,
+                image_size=self.image_size, rank=dd.rank(), num_replicas=dd.world_size(), **self._synthetic)
+        return self.__dict__["_data_provider"]
+
+
+class Div2K_SetXXRunConfig(SyntheticSRRunConfig):
+    """reference :127-160.  The DIV2K/SetXX files (/SSD/div2k_setxx) and torchvision are absent in this
+    environment, so unless `save_path`/dataset directories exist the provider is the synthetic one of the
+    same interface (documented in DESIGN.md; the real provider is the 'next' row 8f-4)."""
+
+    def __init__(self, n_epochs=150, init_lr=0.05, lr_schedule_type="cosine", lr_schedule_param=None,
+                 dataset="div2k_setxx", train_batch_size=256, test_batch_size=500, valid_size=None, opt_type="sgd",
+                 opt_param=None, weight_decay=4e-5, label_smoothing=0.1, no_decay_keys=None, mixup_alpha=None,
+                 model_init="he_fout", validation_frequency=1, print_frequency=10, n_worker=32,
+                 resize_scale=0.08, distort_color="tf", image_size=224, **kwargs):
+        super().__init__(n_epochs, init_lr, lr_schedule_type, lr_schedule_param, dataset, train_batch_size,
+                         test_batch_size, valid_size, opt_type, opt_param, weight_decay, label_smoothing,
+                         no_decay_keys, mixup_alpha, model_init, validation_frequency, print_frequency,
+                         n_worker=n_worker, image_size=image_size,
+                         **{k: v for k, v in kwargs.items() if k in ("n_train_batches", "n_test_batches",
+                                                                     "data_seed", "test_sizes")})
+        self.resize_scale = resize_scale
+        self.distort_color = distort_color
+        self.dataset_root = os.environ.get("OFASR_DIV2K_ROOT", "/SSD/div2k_setxx")

@@ -287,3 +287,25 @@ class MyNetwork(MyModule):
 
     def weight_parameters(self, exclude_set=None):
         return self.get_parameters(exclude_set=exclude_set)
+
+
+def psnr_y_device(output, target):
+    """psnr_y evaluated ON THE DEVICE, bit-for-bit the same quantisation steps (clamp, *255, round-half-even,
+    BT.601 luma in fp64, round) and, for batches > 1, the same pixel count as the reference's
+    make_grid mosaic (2-px zero padding contributes zero error but is counted).
+    Returns a 0-dim fp64 tensor: no host sync until the caller reads it."""
+    def luma(t):
+        u8 = (t.detach().float().clamp(0, 1) * 255.0).round().double()
+        y = (u8[:, 0] * 65.481 + u8[:, 1] * 128.553 + u8[:, 2] * 24.966) / 255.0 + 16.0
+        return y.round()
+
+    n, _, h, w = output.shape
+    sq = ((luma(output) - luma(target)) ** 2).sum()
+    if n == 1:
+        count = h * w
+    else:
+        xmaps = min(int(math.sqrt(n)), n)
+        ymaps = int(math.ceil(float(n) / xmaps))
+        count = ((h + 2) * ymaps + 2) * ((w + 2) * xmaps + 2)
+    mse = sq / count
+    return 20.0 * torch.log10(255.0 / torch.sqrt(mse))

@@ -411,7 +411,69 @@ def gen_metric():
     save("metric.npz", **out)
 
 
+# ------------------------------------------------------------------ a11 progressive-shrinking steps
+def gen_trainer():
+    """two optimizer steps of the progressive-shrinking hot loop (reference progressive_shrinking.py:152-203,
+    transcribed around the REFERENCE net/optimizer because the original hard-codes .cuda()): per step,
+    dynamic_batch_size=2 sub-networks sampled with the reference's seed rule, MSE loss, grads accumulated,
+    Adam (weight-decay groups of sr_run_manager.py:180-191) stepped once."""
+    from ofa.elastic_nn.networks import OFAMobileNetS4
+    from ofa.imagenet_codebase.run_manager.sr_run_manager import RunConfig
+    DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = 1
+    net = OFAMobileNetS4(ks_list=[3, 5, 7], expand_ratio_list=[3, 4, 6], depth_list=[2, 3, 4],
+                         pixelshuffle_depth_list=[2])
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = fill_state_dict(shapes, "s4")
+    net.load_state_dict({k: T(v) for k, v in sd.items()})
+    net.train()
+    cfg = RunConfig(n_epochs=1, init_lr=1e-3, lr_schedule_type="cosine", lr_schedule_param=None, dataset="x",
+                    train_batch_size=2, test_batch_size=1, valid_size=None, opt_type="adam", opt_param=None,
+                    weight_decay=3e-5, label_smoothing=0.0, no_decay_keys="bn#bias", mixup_alpha=None,
+                    model_init="he_fout", validation_frequency=1, print_frequency=1)
+    keys = cfg.no_decay_keys.split("#")
+    opt = cfg.build_optimizer([net.get_parameters(keys, mode="exclude"), net.get_parameters(keys, mode="include")])
+    nBatch, epoch = 2, 0
+    out = {}
+    hr = det_uniform((2, 2, 3, 32, 32), "tr/hr", 0.0, 1.0)
+    x4 = det_uniform((2, 2, 3, 8, 8), "tr/x4", 0.0, 1.0)
+    out["hr"], out["x4"] = hr, x4
+    losses, lrs, sampled = [], [], []
+    for i in range(nBatch):
+        lrs.append(cfg.adjust_learning_rate(opt, epoch, i, nBatch))
+        opt.zero_grad()
+        for sub in range(2):
+            random.seed(int('%d%.3d%.3d' % (epoch * nBatch + i, sub, 0)))
+            s = net.sample_active_subnet()
+            sampled.append({k: v for k, v in s.items()})
+            y = net(T(x4[i]))
+            loss = F.mse_loss(y, T(hr[i]))
+            losses.append(float(loss.detach()))
+            loss.backward()
+        opt.step()
+    out["losses"] = np.array(losses)
+    out["lrs"] = np.array(lrs)
+    names = [n for n, _ in net.named_parameters()]
+    out["w_sum"] = np.array([float(p.detach().double().sum()) for _, p in net.named_parameters()])
+    out["w_l2"] = np.array([float(p.detach().double().pow(2).sum().sqrt()) for _, p in net.named_parameters()])
+    sd0 = fill_state_dict(shapes, "s4")
+    out["w_changed"] = np.array([not np.array_equal(sd0[n], A(p)) for n, p in net.named_parameters()])
+    pd = dict(net.named_parameters())
+    for k in FULL_GRAD_KEYS:
+        out["w_" + k] = A(pd[k])
+    bufs = dict(net.named_buffers())
+    for k in ["blocks.0.mobile_inverted_conv.depth_conv.bn.bn.running_mean",
+              "blocks.0.mobile_inverted_conv.depth_conv.bn.bn.num_batches_tracked",
+              "blocks.15.mobile_inverted_conv.depth_conv.bn.bn.num_batches_tracked",
+              "dec_final_output_conv_block.bn.running_var"]:
+        out["buf_" + k] = A(bufs[k])
+    DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = None
+    save("trainer.npz", **out)
+    with open(os.path.join(HERE, "trainer_meta.json"), "w") as f:
+        json.dump({"param_names": names, "sampled": sampled}, f, indent=1)
+    print("wrote trainer_meta.json")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pwconv", "dwconv", "bn", "pixelshuffle", "mbblock", "s4", "metric"]
+    which = sys.argv[1:] or ["pwconv", "dwconv", "bn", "pixelshuffle", "mbblock", "s4", "metric", "trainer"]
     for w in which:
         globals()["gen_" + w]()
