@@ -117,6 +117,36 @@ int ofasr_pwconv_wgrad(const void* dy, const void* x, float* dw, int64_t ldw, in
                        int64_t Cin, int64_t Cout, int64_t HW, int dtype, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Sliced BatchNorm2d fused with its activation and the residual add  -- replaces, per call site of the
+ * MB block, F.batch_norm on [:C] slices (DynamicBatchNorm2d.bn_forward, dynamic_op.py:148-167) + the
+ * in-place ReLU6 (dynamic_layers.py:44,56) + the shortcut add (proxyless_nets.py:50), forward and
+ * backward.  x, residual, y, dy, dx: [N, C, HW] (`dtype`); all per-channel vectors fp32 of length >= C.
+ *
+ *   bn_stats     per-channel (sum, sum of squares) partials of x into `workspace`
+ *   bn_finalize  training=1: batch mean / biased variance from the partials, running stats updated in
+ *                place (EMA with `momentum`, unbiased variance); training=0: running stats are used.
+ *                Emits mean, invstd, scale = gamma*invstd, shift = beta - mean*scale.
+ *   bn_act_fwd   y = act(x*scale + shift (+ residual));  act: 0 none, 1 ReLU6
+ *   bn_act_bwd   dz = dy masked by the open ReLU6 window (recomputed from x); dgamma = sum dz*xhat,
+ *                dbeta = sum dz; training=1: dx = scale*(dz - dbeta/M - xhat*dgamma/M), training=0:
+ *                dx = scale*dz; dresidual (optional, may be NULL) = dz.
+ * ------------------------------------------------------------------------------------------- */
+size_t ofasr_bn_workspace(int64_t N, int64_t C);
+int ofasr_bn_partials(int64_t N, int64_t C); /* number of partial slabs ofasr_bn_stats writes */
+int ofasr_bn_stats(const void* x, int64_t N, int64_t C, int64_t HW, int dtype, void* workspace,
+                   size_t workspace_bytes, void* stream);
+int ofasr_bn_finalize(const void* workspace, int64_t n_partials, int64_t C, double count, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var, double momentum, double eps,
+                      int training, float* mean, float* invstd, float* scale, float* shift, void* stream);
+int ofasr_bn_act_fwd(const void* x, const void* residual, void* y, const float* scale, const float* shift,
+                     int64_t N, int64_t C, int64_t HW, int act, int dtype, void* stream);
+size_t ofasr_bn_act_bwd_workspace(int64_t N, int64_t C);
+int ofasr_bn_act_bwd(const void* dy, const void* x, const void* residual, void* dx, void* dresidual,
+                     const float* scale, const float* shift, const float* mean, const float* invstd,
+                     float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t HW, int act, int training,
+                     int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

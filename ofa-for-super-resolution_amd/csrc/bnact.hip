@@ -1,0 +1,495 @@
+// bnact.hip -- sliced BatchNorm2d fused with its activation (ReLU6) and the block's residual add.
+//
+// Replaces, per call site of the MB block (reference ofa/elastic_nn/modules/dynamic_layers.py:35-63:
+// DynamicBatchNorm2d -> ReLU6, and proxyless_nets.py:50: + shortcut), the ATen chain
+//     F.batch_norm (dynamic_op.py:163-167)  ->  hardtanh_  ->  add
+// which on the GPU is 3-4 full passes over the mid tensor forward and 4-5 backward, by
+//     forward : one read-only statistics pass + one fused normalise/activate/add pass
+//     backward: one read-only reduction pass (sum dz, sum dz*xhat; dz = dy masked by the ReLU6 window,
+//               recomputed from the PRE-BN tensor) + one fused apply pass.
+// All four are pure HBM streaming kernels (roofline: HBM; algorithmic bytes are listed per kernel).
+// Statistics are reduced through per-block partial slabs in a fixed order => deterministic, no atomics.
+//
+//   bn_stats        reads B*M*C                          (M = N*HW elements per channel, B = elem size)
+//   bn_finalize     O(C)
+//   bn_act_fwd      reads B*M*C (+B*M*C residual), writes B*M*C
+//   bn_bwd_reduce   reads 2*B*M*C
+//   bn_bwd_apply    reads 2*B*M*C, writes B*M*C
+#include "ofasr_common.h"
+
+namespace ofasr {
+
+constexpr int BN_THREADS = 256;
+
+template <typename T> struct Vec;   // 16-byte vector of T
+template <> struct Vec<float> { static constexpr int N = 4; };
+template <> struct Vec<bf16_t> { static constexpr int N = 8; };
+template <> struct Vec<f16_t> { static constexpr int N = 8; };
+
+template <typename T>
+__device__ __forceinline__ void unpack16(const uint4& v, float* out) {
+    if constexpr (sizeof(T) == 4) {
+        out[0] = __uint_as_float(v.x); out[1] = __uint_as_float(v.y);
+        out[2] = __uint_as_float(v.z); out[3] = __uint_as_float(v.w);
+    } else {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            T lo, hi;
+            lo.v = (uint16_t)(w[i] & 0xffffu);
+            hi.v = (uint16_t)(w[i] >> 16);
+            out[2 * i] = to_float(lo);
+            out[2 * i + 1] = to_float(hi);
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 pack16(const float* in) {
+    if constexpr (sizeof(T) == 4) {
+        return make_uint4(__float_as_uint(in[0]), __float_as_uint(in[1]), __float_as_uint(in[2]), __float_as_uint(in[3]));
+    } else {
+        return make_uint4(pack2<T>(in[0], in[1]), pack2<T>(in[2], in[3]), pack2<T>(in[4], in[5]), pack2<T>(in[6], in[7]));
+    }
+}
+
+// deterministic block reduction of two running sums; result valid in thread 0
+__device__ __forceinline__ void block_reduce2(float& a, float& b) {
+    __shared__ float sa[BN_THREADS / 64], sb[BN_THREADS / 64];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sa[w] = a;
+        sb[w] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ra = 0.f, rb = 0.f;
+#pragma unroll
+        for (int i = 0; i < BN_THREADS / 64; ++i) {
+            ra += sa[i];
+            rb += sb[i];
+        }
+        a = ra;
+        b = rb;
+    }
+    __syncthreads();
+}
+
+// work split: grid = (C, P); block (c, p) covers images n = p, p+P, ... of channel c.
+// ----------------------------------------------------------------------------------- bn_stats
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(BN_THREADS) bn_stats_kernel(const T* __restrict__ x, float* __restrict__ partial,
+                                                              int N, int C, int HW, int P) {
+    const int c = blockIdx.x, p = blockIdx.y;
+    float s = 0.f, ss = 0.f;
+    for (int n = p; n < N; n += P) {
+        const T* xp = x + ((long long)n * C + c) * HW;
+        if (VEC) {
+            constexpr int V = Vec<T>::N;
+            const uint4* xv = reinterpret_cast<const uint4*>(xp);
+            for (int i = threadIdx.x; i < HW / V; i += BN_THREADS) {
+                float f[8];
+                unpack16<T>(xv[i], f);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    s += f[j];
+                    ss = fmaf(f[j], f[j], ss);
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += BN_THREADS) {
+                const float v = to_float(xp[i]);
+                s += v;
+                ss = fmaf(v, v, ss);
+            }
+        }
+    }
+    block_reduce2(s, ss);
+    if (threadIdx.x == 0) {
+        partial[((long long)p * C + c) * 2] = s;
+        partial[((long long)p * C + c) * 2 + 1] = ss;
+    }
+}
+
+// -------------------------------------------------------------------------------- bn_finalize
+// mode 0 (train): mean / biased var from the partials; running stats EMA with the unbiased var.
+// mode 1 (eval) : statistics are the running buffers.
+// outputs (length C): mean, invstd, scale = gamma*invstd, shift = beta - mean*scale
+__global__ void __launch_bounds__(64) bn_finalize_kernel(const float* __restrict__ partial, int P, int C, double M,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ running_mean,
+                                                         float* __restrict__ running_var, double momentum, double eps,
+                                                         int training, float* __restrict__ mean_out,
+                                                         float* __restrict__ invstd_out, float* __restrict__ scale,
+                                                         float* __restrict__ shift) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double mean, var;
+    if (training) {
+        double s = 0.0, ss = 0.0;
+        for (int p = 0; p < P; ++p) {
+            s += (double)partial[((long long)p * C + c) * 2];
+            ss += (double)partial[((long long)p * C + c) * 2 + 1];
+        }
+        mean = s / M;
+        var = ss / M - mean * mean;
+        if (var < 0.0) var = 0.0;
+        if (running_mean) {
+            const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+        }
+    } else {
+        mean = (double)running_mean[c];
+        var = (double)running_var[c];
+    }
+    const double invstd = 1.0 / sqrt(var + eps);
+    const double g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = (float)invstd;
+    scale[c] = (float)(g * invstd);
+    shift[c] = (float)(b - mean * g * invstd);
+}
+
+// --------------------------------------------------------------------------------- bn_act_fwd
+// y = act(x*scale[c] + shift[c] (+ res));  act: 0 none, 1 relu6.   grid = (C, N-chunks)
+template <typename T, bool VEC, int ACT, bool RES>
+__global__ void __launch_bounds__(BN_THREADS) bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                                T* __restrict__ y, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int N, int C, int HW,
+                                                                int P) {
+    const int c = blockIdx.x, p = blockIdx.y;
+    const float sc = scale[c], sh = shift[c];
+    for (int n = p; n < N; n += P) {
+        const long long off = ((long long)n * C + c) * HW;
+        if (VEC) {
+            constexpr int V = Vec<T>::N;
+            const uint4* xv = reinterpret_cast<const uint4*>(x + off);
+            const uint4* rv = RES ? reinterpret_cast<const uint4*>(res + off) : nullptr;
+            uint4* yv = reinterpret_cast<uint4*>(y + off);
+            for (int i = threadIdx.x; i < HW / V; i += BN_THREADS) {
+                float f[8], r[8];
+                unpack16<T>(xv[i], f);
+                if (RES) unpack16<T>(rv[i], r);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    float v = fmaf(f[j], sc, sh);
+                    if (RES) v += r[j];
+                    if (ACT == 1) v = fminf(fmaxf(v, 0.f), 6.f);
+                    f[j] = v;
+                }
+                yv[i] = pack16<T>(f);
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += BN_THREADS) {
+                float v = fmaf(to_float(x[off + i]), sc, sh);
+                if (RES) v += to_float(res[off + i]);
+                if (ACT == 1) v = fminf(fmaxf(v, 0.f), 6.f);
+                y[off + i] = from_float<T>(v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ bn_bwd_reduce
+// dz = dy * [0 < x*scale+shift (+res) < 6]  (ACT == 1; the window is evaluated on the fp32 pre-activation,
+// hardtanh_backward semantics);  partial[p][c] = (sum dz, sum dz * xhat),  xhat = (x - mean) * invstd
+template <typename T, bool VEC, int ACT, bool RES>
+__global__ void __launch_bounds__(BN_THREADS) bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                   const T* __restrict__ res,
+                                                                   const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd,
+                                                                   float* __restrict__ partial, int N, int C, int HW,
+                                                                   int P) {
+    const int c = blockIdx.x, p = blockIdx.y;
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    float s = 0.f, sx = 0.f;
+    for (int n = p; n < N; n += P) {
+        const long long off = ((long long)n * C + c) * HW;
+        if (VEC) {
+            constexpr int V = Vec<T>::N;
+            const uint4* xv = reinterpret_cast<const uint4*>(x + off);
+            const uint4* dv = reinterpret_cast<const uint4*>(dy + off);
+            const uint4* rv = RES ? reinterpret_cast<const uint4*>(res + off) : nullptr;
+            for (int i = threadIdx.x; i < HW / V; i += BN_THREADS) {
+                float f[8], g[8], r[8];
+                unpack16<T>(xv[i], f);
+                unpack16<T>(dv[i], g);
+                if (RES) unpack16<T>(rv[i], r);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    float dz = g[j];
+                    if (ACT == 1) {
+                        float pre = fmaf(f[j], sc, sh);
+                        if (RES) pre += r[j];
+                        dz = (pre > 0.f && pre < 6.f) ? dz : 0.f;
+                    }
+                    s += dz;
+                    sx = fmaf(dz, (f[j] - mu) * is, sx);
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += BN_THREADS) {
+                const float xf = to_float(x[off + i]);
+                float dz = to_float(dy[off + i]);
+                if (ACT == 1) {
+                    float pre = fmaf(xf, sc, sh);
+                    if (RES) pre += to_float(res[off + i]);
+                    dz = (pre > 0.f && pre < 6.f) ? dz : 0.f;
+                }
+                s += dz;
+                sx = fmaf(dz, (xf - mu) * is, sx);
+            }
+        }
+    }
+    block_reduce2(s, sx);
+    if (threadIdx.x == 0) {
+        partial[((long long)p * C + c) * 2] = s;
+        partial[((long long)p * C + c) * 2 + 1] = sx;
+    }
+}
+
+// dgamma[c] = sum dz*xhat, dbeta[c] = sum dz; coefficients of the apply pass:
+//   train: dx = k1*dz + k2*x + k3  with k1 = scale, k2 = -scale*invstd*dgamma/M, k3 = -scale*dbeta/M - k2*mean
+//   eval : dx = scale*dz
+__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __restrict__ partial, int P, int C, double M,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, int training,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ coef) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, sx = 0.0;
+    for (int p = 0; p < P; ++p) {
+        s += (double)partial[((long long)p * C + c) * 2];
+        sx += (double)partial[((long long)p * C + c) * 2 + 1];
+    }
+    if (dgamma) dgamma[c] = (float)sx;
+    if (dbeta) dbeta[c] = (float)s;
+    const double k1 = (double)scale[c];
+    double k2 = 0.0, k3 = 0.0;
+    if (training) {
+        k2 = -k1 * (double)invstd[c] * sx / M;
+        k3 = -k1 * s / M - k2 * (double)mean[c];
+    }
+    coef[3 * c] = (float)k1;
+    coef[3 * c + 1] = (float)k2;
+    coef[3 * c + 2] = (float)k3;
+}
+
+// dx = k1*dz + k2*x + k3;  optionally also emits dres = dz (gradient of the residual branch)
+template <typename T, bool VEC, int ACT, bool RES>
+__global__ void __launch_bounds__(BN_THREADS) bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                  const T* __restrict__ res, T* __restrict__ dx,
+                                                                  T* __restrict__ dres, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift,
+                                                                  const float* __restrict__ coef, int N, int C, int HW,
+                                                                  int P) {
+    const int c = blockIdx.x, p = blockIdx.y;
+    const float sc = scale[c], sh = shift[c];
+    const float k1 = coef[3 * c], k2 = coef[3 * c + 1], k3 = coef[3 * c + 2];
+    for (int n = p; n < N; n += P) {
+        const long long off = ((long long)n * C + c) * HW;
+        if (VEC) {
+            constexpr int V = Vec<T>::N;
+            const uint4* xv = reinterpret_cast<const uint4*>(x + off);
+            const uint4* dv = reinterpret_cast<const uint4*>(dy + off);
+            const uint4* rv = RES ? reinterpret_cast<const uint4*>(res + off) : nullptr;
+            uint4* ov = reinterpret_cast<uint4*>(dx + off);
+            uint4* orv = (RES && dres) ? reinterpret_cast<uint4*>(dres + off) : nullptr;
+            for (int i = threadIdx.x; i < HW / V; i += BN_THREADS) {
+                float f[8], g[8], r[8], o[8];
+                unpack16<T>(xv[i], f);
+                unpack16<T>(dv[i], g);
+                if (RES) unpack16<T>(rv[i], r);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    float dz = g[j];
+                    if (ACT == 1) {
+                        float pre = fmaf(f[j], sc, sh);
+                        if (RES) pre += r[j];
+                        dz = (pre > 0.f && pre < 6.f) ? dz : 0.f;
+                    }
+                    g[j] = dz;
+                    o[j] = fmaf(k1, dz, fmaf(k2, f[j], k3));
+                }
+                ov[i] = pack16<T>(o);
+                if (orv) orv[i] = pack16<T>(g);
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += BN_THREADS) {
+                const float xf = to_float(x[off + i]);
+                float dz = to_float(dy[off + i]);
+                if (ACT == 1) {
+                    float pre = fmaf(xf, sc, sh);
+                    if (RES) pre += to_float(res[off + i]);
+                    dz = (pre > 0.f && pre < 6.f) ? dz : 0.f;
+                }
+                dx[off + i] = from_float<T>(fmaf(k1, dz, fmaf(k2, xf, k3)));
+                if (RES && dres) dres[off + i] = from_float<T>(dz);
+            }
+        }
+    }
+}
+
+static int bn_parts(int64_t N, int64_t C) {
+    // enough blocks to fill the chip (256 CUs x ~8 blocks), at most one image per part
+    int64_t want = cdiv(2048, C > 0 ? C : 1);
+    if (want < 1) want = 1;
+    if (want > N) want = N;
+    return (int)want;
+}
+
+static int check_bn(const char* name, int64_t N, int64_t C, int64_t HW, int dtype) {
+    OFASR_REQUIRE(N > 0 && C > 0 && HW > 0, OFASR_ERR_INVALID_ARG, "%s: bad shape N=%lld C=%lld HW=%lld", name,
+                  (long long)N, (long long)C, (long long)HW);
+    OFASR_REQUIRE(dtype == OFASR_F32 || dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_INVALID_ARG,
+                  "%s: bad dtype %d", name, dtype);
+    OFASR_REQUIRE(N <= INT32_MAX && C <= 65535 * 32 && HW <= INT32_MAX, OFASR_ERR_UNSUPPORTED, "%s: too large", name);
+    return OFASR_OK;
+}
+
+static bool vec_ok(int64_t HW, int dtype, const void* a, const void* b, const void* c, const void* d) {
+    const int V = dtype == OFASR_F32 ? 4 : 8;
+    uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+                     reinterpret_cast<uintptr_t>(d);
+    return (HW % V) == 0 && (bits & 15) == 0;
+}
+
+}  // namespace ofasr
+
+using namespace ofasr;
+
+#define OFASR_BN_DISPATCH_T(dtype, CALL)      \
+    switch (dtype) {                          \
+        case OFASR_F32: { using T = float; CALL; } break;   \
+        case OFASR_F16: { using T = f16_t; CALL; } break;   \
+        default: { using T = bf16_t; CALL; } break;         \
+    }
+
+OFASR_EXPORT size_t ofasr_bn_workspace(int64_t N, int64_t C) {
+    if (N <= 0 || C <= 0) return 0;
+    return (size_t)bn_parts(N, C) * (size_t)C * 2 * sizeof(float);
+}
+
+OFASR_EXPORT int ofasr_bn_stats(const void* x, int64_t N, int64_t C, int64_t HW, int dtype, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    const char* name = "ofasr_bn_stats";
+    int rc = check_bn(name, N, C, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(x && workspace && workspace_bytes >= ofasr_bn_workspace(N, C), OFASR_ERR_WORKSPACE,
+                  "%s: null input or workspace too small", name);
+    const int P = bn_parts(N, C);
+    dim3 grid((unsigned)C, (unsigned)P);
+    hipStream_t st = as_stream(stream);
+    const bool v = vec_ok(HW, dtype, x, nullptr, nullptr, nullptr);
+    OFASR_BN_DISPATCH_T(dtype, {
+        if (v) hipLaunchKernelGGL((bn_stats_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)x,
+                                  (float*)workspace, (int)N, (int)C, (int)HW, P);
+        else hipLaunchKernelGGL((bn_stats_kernel<T, false>), grid, dim3(BN_THREADS), 0, st, (const T*)x,
+                                (float*)workspace, (int)N, (int)C, (int)HW, P);
+    });
+    return check_launch(name);
+}
+
+OFASR_EXPORT int ofasr_bn_finalize(const void* workspace, int64_t n_partials, int64_t C, double count,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   double momentum, double eps, int training, float* mean, float* invstd, float* scale,
+                                   float* shift, void* stream) {
+    const char* name = "ofasr_bn_finalize";
+    OFASR_REQUIRE(C > 0 && mean && invstd && scale && shift, OFASR_ERR_INVALID_ARG, "%s: null output or C<=0", name);
+    OFASR_REQUIRE(training ? (workspace != nullptr && n_partials > 0 && count > 0) : (running_mean && running_var),
+                  OFASR_ERR_INVALID_ARG, "%s: missing statistics source", name);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, as_stream(stream),
+                       (const float*)workspace, (int)n_partials, (int)C, count, gamma, beta, running_mean, running_var,
+                       momentum, eps, training, mean, invstd, scale, shift);
+    return check_launch(name);
+}
+
+OFASR_EXPORT int ofasr_bn_partials(int64_t N, int64_t C) { return (N > 0 && C > 0) ? bn_parts(N, C) : 0; }
+
+OFASR_EXPORT int ofasr_bn_act_fwd(const void* x, const void* residual, void* y, const float* scale, const float* shift,
+                                  int64_t N, int64_t C, int64_t HW, int act, int dtype, void* stream) {
+    const char* name = "ofasr_bn_act_fwd";
+    int rc = check_bn(name, N, C, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(x && y && scale && shift, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(act == 0 || act == 1, OFASR_ERR_UNSUPPORTED, "%s: act %d not in {0 none, 1 relu6}", name, act);
+    const int P = bn_parts(N, C);
+    dim3 grid((unsigned)C, (unsigned)P);
+    hipStream_t st = as_stream(stream);
+    const bool v = vec_ok(HW, dtype, x, residual, y, nullptr);
+#define OFASR_BNF(VEC, ACT, RES)                                                                                   \
+    hipLaunchKernelGGL((bn_act_fwd_kernel<T, VEC, ACT, RES>), grid, dim3(BN_THREADS), 0, st, (const T*)x,          \
+                       (const T*)residual, (T*)y, scale, shift, (int)N, (int)C, (int)HW, P)
+    OFASR_BN_DISPATCH_T(dtype, {
+        if (v) {
+            if (act == 1) { if (residual) OFASR_BNF(true, 1, true); else OFASR_BNF(true, 1, false); }
+            else { if (residual) OFASR_BNF(true, 0, true); else OFASR_BNF(true, 0, false); }
+        } else {
+            if (act == 1) { if (residual) OFASR_BNF(false, 1, true); else OFASR_BNF(false, 1, false); }
+            else { if (residual) OFASR_BNF(false, 0, true); else OFASR_BNF(false, 0, false); }
+        }
+    });
+#undef OFASR_BNF
+    return check_launch(name);
+}
+
+OFASR_EXPORT int ofasr_bn_act_bwd(const void* dy, const void* x, const void* residual, void* dx, void* dresidual,
+                                  const float* scale, const float* shift, const float* mean, const float* invstd,
+                                  float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t HW, int act, int training,
+                                  int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    const char* name = "ofasr_bn_act_bwd";
+    int rc = check_bn(name, N, C, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(dy && x && dx && scale && shift && mean && invstd, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(act == 0 || act == 1, OFASR_ERR_UNSUPPORTED, "%s: act %d not in {0 none, 1 relu6}", name, act);
+    const int P = bn_parts(N, C);
+    const size_t need = (size_t)P * C * 2 * sizeof(float) + (size_t)C * 3 * sizeof(float);
+    OFASR_REQUIRE(workspace && workspace_bytes >= need, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", name,
+                  workspace_bytes, need);
+    float* partial = (float*)workspace;
+    float* coef = partial + (size_t)P * C * 2;
+    dim3 grid((unsigned)C, (unsigned)P);
+    hipStream_t st = as_stream(stream);
+    const bool v = vec_ok(HW, dtype, dy, x, residual, dx) && ((reinterpret_cast<uintptr_t>(dresidual) & 15) == 0);
+#define OFASR_BNR(VEC, ACT, RES)                                                                                     \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, ACT, RES>), grid, dim3(BN_THREADS), 0, st, (const T*)dy,        \
+                       (const T*)x, (const T*)residual, scale, shift, mean, invstd, partial, (int)N, (int)C, (int)HW, P)
+#define OFASR_BNA(VEC, ACT, RES)                                                                                     \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC, ACT, RES>), grid, dim3(BN_THREADS), 0, st, (const T*)dy,         \
+                       (const T*)x, (const T*)residual, (T*)dx, (T*)dresidual, scale, shift, coef, (int)N, (int)C,   \
+                       (int)HW, P)
+#define OFASR_BN_BOTH(MACRO)                                                                              \
+    OFASR_BN_DISPATCH_T(dtype, {                                                                          \
+        if (v) {                                                                                          \
+            if (act == 1) { if (residual) MACRO(true, 1, true); else MACRO(true, 1, false); }             \
+            else { if (residual) MACRO(true, 0, true); else MACRO(true, 0, false); }                      \
+        } else {                                                                                          \
+            if (act == 1) { if (residual) MACRO(false, 1, true); else MACRO(false, 1, false); }           \
+            else { if (residual) MACRO(false, 0, true); else MACRO(false, 0, false); }                    \
+        }                                                                                                 \
+    })
+    OFASR_BN_BOTH(OFASR_BNR);
+    rc = check_launch(name);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, partial, P, (int)C,
+                       (double)N * (double)HW, scale, mean, invstd, training, dgamma, dbeta, coef);
+    rc = check_launch(name);
+    if (rc) return rc;
+    OFASR_BN_BOTH(OFASR_BNA);
+#undef OFASR_BNR
+#undef OFASR_BNA
+#undef OFASR_BN_BOTH
+    return check_launch(name);
+}
+
+OFASR_EXPORT size_t ofasr_bn_act_bwd_workspace(int64_t N, int64_t C) {
+    if (N <= 0 || C <= 0) return 0;
+    return (size_t)bn_parts(N, C) * C * 2 * sizeof(float) + (size_t)C * 3 * sizeof(float);
+}

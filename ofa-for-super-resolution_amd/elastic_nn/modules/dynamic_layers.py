@@ -12,6 +12,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
+from ... import ops
 from ...layers import MBInvertedConvLayer
 from ...utils import MyModule, build_activation, get_net_device, int2list, make_divisible
 from ..utils import adjust_bn_according_to_idx, copy_bn
@@ -27,6 +28,7 @@ def _conv_bn_act(conv, bn, act_func):
 
 
 class DynamicMBConvLayer(MyModule):
+    accepts_residual = True
     """expand 1x1 (C_in -> mid) -> BN -> act -> depthwise kxk -> BN -> act -> project 1x1 (mid -> C_out) -> BN
     with mid = make_divisible(round(C_in * active_expand_ratio), 8) and k = active_kernel_size."""
 
@@ -61,14 +63,24 @@ class DynamicMBConvLayer(MyModule):
     def active_middle_channel(self, in_channel):
         return make_divisible(round(in_channel * self.active_expand_ratio), 8)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """`residual` (optional) is added to the block output inside the last BN pass -- what
+        MobileInvertedResidualBlock does with its identity shortcut (reference proxyless_nets.py:50)."""
         if self.inverted_bottleneck is not None:
             self.inverted_bottleneck.conv.active_out_channel = self.active_middle_channel(x.size(1))
         self.depth_conv.conv.active_kernel_size = self.active_kernel_size
         self.point_linear.conv.active_out_channel = self.active_out_channel
+        fused = ops.FUSED_BN and self.act_func == "relu6" and not DynamicBatchNorm2d.SET_RUNNING_STATISTICS
+        if not fused:
+            if self.inverted_bottleneck is not None:
+                x = self.inverted_bottleneck(x)
+            x = self.point_linear(self.depth_conv(x))
+            return x if residual is None else x + residual
+        # conv -> [BN + ReLU6] fused passes; the last BN also folds in the shortcut add
         if self.inverted_bottleneck is not None:
-            x = self.inverted_bottleneck(x)
-        return self.point_linear(self.depth_conv(x))
+            x = ops.bn_act(self.inverted_bottleneck.conv(x), self.inverted_bottleneck.bn.bn, ops.ACT_RELU6)
+        x = ops.bn_act(self.depth_conv.conv(x), self.depth_conv.bn.bn, ops.ACT_RELU6)
+        return ops.bn_act(self.point_linear.conv(x), self.point_linear.bn.bn, ops.ACT_NONE, residual)
 
     @property
     def module_str(self):

@@ -118,4 +118,6 @@ class DynamicBatchNorm2d(nn.Module):
             bn.bias[:feature_dim], bn.training or not bn.track_running_stats, factor, bn.eps)
 
     def forward(self, x):
+        if ops.FUSED_BN and not DynamicBatchNorm2d.SET_RUNNING_STATISTICS:
+            return ops.bn_act(x, self.bn, ops.ACT_NONE)      # HIP statistics + apply passes
         return self.bn_forward(x, self.bn, x.size(1))

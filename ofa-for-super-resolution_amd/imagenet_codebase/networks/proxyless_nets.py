@@ -1,6 +1,6 @@
 """MobileInvertedResidualBlock (reference ofa/imagenet_codebase/networks/proxyless_nets.py:36-72):
 `mobile_inverted_conv(x) + shortcut(x)`.  The ImageNet ProxylessNAS networks are out of scope."""
-from ...layers import ZeroLayer, set_layer_from_config
+from ...layers import IdentityLayer, ZeroLayer, set_layer_from_config
 from ...utils import MyModule
 
 
@@ -17,6 +17,8 @@ class MobileInvertedResidualBlock(MyModule):
             return x
         if skip is None or isinstance(skip, ZeroLayer):
             return conv(x)
+        if isinstance(skip, IdentityLayer) and not skip._modules and getattr(conv, "accepts_residual", False):
+            return conv(x, residual=x)      # shortcut add fused into the block's last BN pass
         return conv(x) + skip(x)
 
     @property

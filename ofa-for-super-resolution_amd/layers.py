@@ -100,6 +100,18 @@ class ConvLayer(My2DLayer):
                                           stride=self.stride, padding=pad, dilation=self.dilation,
                                           groups=self.groups, bias=self.bias))
 
+    def forward(self, x):
+        # conv (MIOpen) -> fused BatchNorm(+ReLU6) HIP passes -> remaining activation (PixelShuffle ...)
+        if not (ops.FUSED_BN and self.ops_order == "weight_bn_act" and self.use_bn and self.dropout_rate == 0
+                and x.is_cuda):
+            return super().forward(x)
+        x = self.conv(x)
+        if self.act_func == "relu6":
+            return ops.bn_act(x, self.bn, ops.ACT_RELU6)
+        x = ops.bn_act(x, self.bn, ops.ACT_NONE)
+        act = self._modules.get("act", None)
+        return x if act is None else act(x)
+
     @property
     def module_str(self):
         ks = (self.kernel_size, self.kernel_size) if isinstance(self.kernel_size, int) else self.kernel_size

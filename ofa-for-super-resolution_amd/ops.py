@@ -65,6 +65,7 @@ class KernelTimer(object):
 
 
 TIMER = None
+FUSED_BN = True    # BatchNorm(+ReLU6)(+residual) through the fused HIP passes; False = ATen F.batch_norm chain
 
 
 class _timed(object):
@@ -298,3 +299,95 @@ class PWConvFn(Function):
 
 def pwconv(x, w_full, cout):
     return PWConvFn.apply(x, w_full, cout)
+
+
+# ------------------------------------------------------------------- BatchNorm + act (+ residual)
+ACT_NONE, ACT_RELU6 = 0, 1
+
+
+class BNActFn(Function):
+    """act(BatchNorm2d_[:C](x) (+ residual)) in two HIP passes (statistics, fused apply) and its backward in
+    two (reduction, fused apply) -- replaces F.batch_norm on parameter slices (reference dynamic_op.py:148-167)
+    + in-place ReLU6 (dynamic_layers.py:44,56) + the shortcut add (proxyless_nets.py:50).
+
+    forward(x, weight, bias, running_mean, running_var, training, momentum, eps, act, residual)
+      weight/bias/running_*: the MAX-size parameters / buffers; the first C = x.size(1) entries are used and
+      (training) running_* [:C] are updated in place.  Gradients of weight / bias are dense max-size
+      tensors with zeros beyond C (what autograd of the slice gives in the reference)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act, residual):
+        _gpu(x, weight, bias, running_mean, running_var, residual)
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        HW = H * W
+        L = _C.lib()
+        dev = x.device
+        w = _f32_param(weight)
+        b = _f32_param(bias)
+        stats = torch.empty((4, C), dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
+        mean, invstd, scale, shift = stats[0], stats[1], stats[2], stats[3]
+        wst = None
+        if training:
+            wst, wsp, wsn = _ws(L.ofasr_bn_workspace(N, C), dev)
+            with _timed("bn_stats", x.numel() * x.element_size()):
+                _C.check(L.ofasr_bn_stats(_p(x), N, C, HW, _dt(x), wsp, wsn, _stream()), "bn_stats")
+            nparts = L.ofasr_bn_partials(N, C)
+        else:
+            wsp, nparts = ctypes.c_void_p(None), 0
+        rm = _p(running_mean) if running_mean is not None else ctypes.c_void_p(None)
+        rv = _p(running_var) if running_var is not None else ctypes.c_void_p(None)
+        _C.check(L.ofasr_bn_finalize(wsp, nparts, C, float(N * HW), _p(w), _p(b), rm, rv, float(momentum), float(eps),
+                                     1 if training else 0, _p(mean), _p(invstd), _p(scale), _p(shift), _stream()),
+                 "bn_finalize")
+        if residual is not None:
+            residual = residual.contiguous()
+            if residual.shape != x.shape or residual.dtype != x.dtype:
+                raise _C.OfasrError("bn_act: residual %s/%s does not match x %s/%s" % (
+                    tuple(residual.shape), residual.dtype, tuple(x.shape), x.dtype))
+        y = torch.empty_like(x)
+        rp = _p(residual) if residual is not None else ctypes.c_void_p(None)
+        with _timed("bn_act_fwd", (2 + (residual is not None)) * x.numel() * x.element_size()):
+            _C.check(L.ofasr_bn_act_fwd(_p(x), rp, _p(y), _p(scale), _p(shift), N, C, HW, act, _dt(x), _stream()),
+                     "bn_act_fwd")
+        keep_res = residual if (residual is not None and act != ACT_NONE) else None
+        ctx.save_for_backward(x, stats, keep_res)
+        ctx.meta = (bool(training), act, residual is not None, tuple(weight.shape))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, stats, res = ctx.saved_tensors
+        training, act, has_res, wshape = ctx.meta
+        N, C, H, W = x.shape
+        HW = H * W
+        L = _C.lib()
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.zeros(wshape, dtype=torch.float32, device=x.device)
+        dbeta = torch.zeros(wshape, dtype=torch.float32, device=x.device)
+        dres = None
+        if has_res:
+            # without an activation the residual gradient IS dy; with one it is the masked dy
+            dres = torch.empty_like(x) if act != ACT_NONE else dy
+        wst, wsp, wsn = _ws(L.ofasr_bn_act_bwd_workspace(N, C), x.device)
+        rp = _p(res) if res is not None else ctypes.c_void_p(None)
+        drp = _p(dres) if (has_res and act != ACT_NONE) else ctypes.c_void_p(None)
+        with _timed("bn_act_bwd", 5 * x.numel() * x.element_size()):
+            _C.check(L.ofasr_bn_act_bwd(_p(dy), _p(x), rp, _p(dx), drp, _p(stats[2]), _p(stats[3]), _p(stats[0]),
+                                        _p(stats[1]), _p(dgamma), _p(dbeta), N, C, HW, act, 1 if training else 0,
+                                        _dt(x), wsp, wsn, _stream()), "bn_act_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None, None, dres
+
+
+def bn_act(x, bn, act=ACT_NONE, residual=None):
+    """apply nn.BatchNorm2d `bn` (its first x.size(1) channels) + activation (+ residual) through the fused
+    HIP kernels, with nn.BatchNorm2d's bookkeeping (num_batches_tracked, momentum=None -> cumulative average)."""
+    training = bn.training or not bn.track_running_stats
+    factor = 0.0
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+        factor = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
+    return BNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, factor, bn.eps, act,
+                         residual)

@@ -1,0 +1,137 @@
+"""GPU parity of the fused BatchNorm(+ReLU6)(+residual) kernels (C ABI ofasr_bn_*) against the CPU oracle's
+sliced BatchNorm (oracle/ofasr_oracle.c ora_bn_*, pinned to the reference by tests/golden/bn.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import amd, assert_close
+from detfill import det_uniform, fill_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _bn(cmax, momentum=0.1, prefix="bnfix"):
+    bn = torch.nn.BatchNorm2d(cmax, momentum=momentum, eps=1e-5)
+    sd = fill_state_dict({"weight": (cmax,), "bias": (cmax,), "running_mean": (cmax,), "running_var": (cmax,)}, prefix)
+    bn.weight.data.copy_(torch.from_numpy(sd["weight"]))
+    bn.bias.data.copy_(torch.from_numpy(sd["bias"]))
+    bn.running_mean.copy_(torch.from_numpy(sd["running_mean"]))
+    bn.running_var.copy_(torch.from_numpy(sd["running_var"]))
+    return bn, sd
+
+
+def _tol(dtype):
+    return {torch.float32: (5e-5, 5e-6), torch.bfloat16: (1.5e-2, 1.5e-2), torch.float16: (3e-3, 3e-3)}[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("act", [0, 1])
+@pytest.mark.parametrize("res", [False, True])
+@pytest.mark.parametrize("shape", [(3, 16, 5, 6), (2, 24, 8, 8), (4, 7, 3, 5)])
+def test_bn_act_vs_oracle(ora, dtype, training, act, res, shape):
+    ops = amd("ops")
+    N, C, H, W = shape
+    cmax = 24
+    bn, sd = _bn(cmax)
+    bn.to(DEV).train(training)
+    x = torch.from_numpy(det_uniform(shape, "bna/x%s" % (shape,), -2.0, 2.0)).to(dtype)
+    r = torch.from_numpy(det_uniform(shape, "bna/r%s" % (shape,), -1.0, 1.0)).to(dtype) if res else None
+    dy = torch.from_numpy(det_uniform(shape, "bna/dy%s" % (shape,))).to(dtype)
+    xg = x.to(DEV).requires_grad_(True)
+    rg = r.to(DEV).requires_grad_(True) if res else None
+    y = ops.bn_act(xg, bn, act, rg)
+    # oracle on the same (rounded) inputs
+    rm, rv = sd["running_mean"].copy(), sd["running_var"].copy()
+    xf = x.float().numpy()
+    yb, mean, invstd = ora.bn_fwd(xf, sd["weight"], sd["bias"], rm, rv, training)
+    pre = yb + (r.float().numpy() if res else 0.0)
+    y_ref = np.clip(pre, 0.0, 6.0) if act else pre
+    rt, at = _tol(dtype)
+    assert_close(y.detach().float().cpu().numpy(), y_ref, rt, at, "y")
+    if training:
+        assert_close(bn.running_mean.cpu().numpy(), rm, 1e-5, 1e-6, "running_mean")
+        assert_close(bn.running_var.cpu().numpy(), rv, 1e-5, 1e-6, "running_var")
+        assert int(bn.num_batches_tracked) == 1
+        assert np.array_equal(bn.running_mean.cpu().numpy()[C:], sd["running_mean"][C:])
+    y.backward(dy.to(DEV))
+    dyf = dy.float().numpy()
+    dz = dyf * ((pre > 0) & (pre < 6)) if act else dyf
+    if training:
+        dx_ref, dg_ref, db_ref = ora.bn_bwd_train(dz, xf, sd["weight"])
+    else:
+        g = sd["weight"][:C].reshape(1, C, 1, 1)
+        istd = (1.0 / np.sqrt(sd["running_var"][:C].astype(np.float64) + 1e-5)).reshape(1, C, 1, 1)
+        mu = sd["running_mean"][:C].astype(np.float64).reshape(1, C, 1, 1)
+        dx_ref = (dz * g * istd).astype(np.float32)
+        dg_ref = (dz * (xf - mu) * istd).sum(axis=(0, 2, 3)).astype(np.float32)
+        db_ref = dz.sum(axis=(0, 2, 3)).astype(np.float32)
+    # near the ReLU6 window edges a 16-bit rounding of `pre` may flip the mask: compare away from the edges
+    safe = np.ones_like(pre, bool)
+    if act and dtype != torch.float32:
+        safe = (np.abs(pre) > 0.05) & (np.abs(pre - 6) > 0.05)
+    if dtype == torch.float32 or not training:
+        got = xg.grad.float().cpu().numpy()
+        assert_close(np.where(safe, got, 0), np.where(safe, dx_ref, 0), 5 * rt, 5 * at, "dx")
+    assert_close(bn.weight.grad.cpu().numpy()[:C], dg_ref, 5 * rt, 20 * at, "dgamma")
+    assert_close(bn.bias.grad.cpu().numpy()[:C], db_ref, 5 * rt, 20 * at, "dbeta")
+    assert np.all(bn.weight.grad.cpu().numpy()[C:] == 0) and np.all(bn.bias.grad.cpu().numpy()[C:] == 0)
+    if res:
+        assert_close(np.where(safe, rg.grad.float().cpu().numpy(), 0), np.where(safe, dz, 0), 1e-6, 1e-6, "dres")
+
+
+def test_bn_golden_reference(golden):
+    """the same goldens that pin the oracle (reference DynamicBatchNorm2d fwd/bwd, train and eval)."""
+    dop = amd("elastic_nn.modules.dynamic_op")
+    g = golden("bn.npz")
+    for C in (16, 24):
+        for training in (True, False):
+            m = dop.DynamicBatchNorm2d(24)
+            m.bn.momentum, m.bn.eps = 0.1, 1e-5
+            sd = fill_state_dict({"bn.weight": (24,), "bn.bias": (24,), "bn.running_mean": (24,),
+                                  "bn.running_var": (24,)}, "bnfix")
+            m.bn.weight.data.copy_(torch.from_numpy(sd["bn.weight"]))
+            m.bn.bias.data.copy_(torch.from_numpy(sd["bn.bias"]))
+            m.bn.running_mean.copy_(torch.from_numpy(sd["bn.running_mean"]))
+            m.bn.running_var.copy_(torch.from_numpy(sd["bn.running_var"]))
+            m.to(DEV).train(training)
+            x = torch.from_numpy(det_uniform((3, C, 5, 6), "bn/x%d" % C, -2.0, 2.0)).to(DEV).requires_grad_(True)
+            y = m(x)
+            tag = "c%d_%s" % (C, "train" if training else "eval")
+            assert_close(y.detach().cpu().numpy(), g["y_" + tag], 5e-5, 5e-6, "y")
+            y.backward(torch.from_numpy(det_uniform(tuple(y.shape), "bn/dy%d" % C)).to(DEV))
+            assert_close(x.grad.cpu().numpy(), g["dx_" + tag], 1e-4, 1e-5, "dx")
+            assert_close(m.bn.weight.grad.cpu().numpy(), g["dgamma_" + tag], 5e-5, 5e-5, "dgamma")
+            assert_close(m.bn.bias.grad.cpu().numpy(), g["dbeta_" + tag], 5e-5, 5e-5, "dbeta")
+            assert_close(m.bn.running_mean.cpu().numpy(), g["rm_" + tag], 1e-5, 1e-6, "rm")
+            assert_close(m.bn.running_var.cpu().numpy(), g["rv_" + tag], 1e-5, 1e-6, "rv")
+            assert int(m.bn.num_batches_tracked) == int(g["nbt_" + tag])
+
+
+def test_fused_and_modular_paths_agree():
+    ops = amd("ops")
+    dop = amd("elastic_nn.modules.dynamic_op")
+    dop.DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = 1
+    net = amd("elastic_nn.networks").OFAMobileNetS4(ks_list=[3, 5, 7], expand_ratio_list=[3, 4, 6],
+                                                    depth_list=[2, 3, 4], pixelshuffle_depth_list=[1, 2])
+    torch.manual_seed(0)
+    net.init_model("he_fout")
+    net.to(DEV).train()
+    net.set_active_subnet(ks=5, e=4, d=3, pixel_d=2)
+    x = torch.rand(2, 3, 16, 12, device=DEV)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    outs = []
+    for fused in (True, False):
+        net.load_state_dict(sd)
+        net.zero_grad()
+        ops.FUSED_BN = fused
+        try:
+            y = net(x)
+            y.square().mean().backward()
+        finally:
+            ops.FUSED_BN = True
+        outs.append((y.detach().clone(), net.blocks[0].mobile_inverted_conv.depth_conv.conv.conv.weight.grad.clone(),
+                     net.blocks[0].mobile_inverted_conv.depth_conv.bn.bn.running_var.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-2, 2e-3 * float(b.abs().max()) + 1e-8, "fused vs modular")
