@@ -218,6 +218,261 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_wgrad_kernel(const T* __rest
     }
 }
 
+// =================================================================================================
+// Vector ("row-group") kernels: 8-16 bytes per lane, one plane slab per wave.
+//
+// The strip kernels above move one element per lane per row (128-256 B per wave instruction); at the
+// MB stack's plane sizes that is latency-bound long before HBM (Little's law: too few bytes in flight).
+// Here a lane owns PXL adjacent pixels of a row, G = W/PXL lanes cover one image row, and the gpw = 64/G
+// lane groups of a wave take gpw consecutive row chunks (R rows each) of the SAME plane, so
+//   * every wave load/store instruction moves gpw full rows (512 B - 1 KiB), K of them in flight per lane;
+//   * the K*K taps of the plane's channel are wave-uniform and sit in SGPRs;
+//   * column neighbours come from the adjacent lane with 2*PAD shuffles per PXL outputs.
+// PXL is 16 bytes' worth of pixels for K <= 3 (bandwidth-bound) and 4 pixels for K >= 5, where the 25-49
+// FMAs per output make the kernel VALU-bound and the K*PXL running sums must stay in registers at high
+// occupancy.  Requires W % PXL == 0, W/PXL <= 64 and suitably aligned tensors; else the strip kernels run.
+// =================================================================================================
+template <typename T, int PXL> struct PxIO;   // PXL pixels of type T <-> floats
+template <> struct PxIO<float, 4> {
+    typedef uint4 raw_t;
+    static __device__ __forceinline__ raw_t zero() { return make_uint4(0, 0, 0, 0); }
+    static __device__ __forceinline__ void unpack(const raw_t& v, float* o) {
+        o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+    }
+    static __device__ __forceinline__ raw_t pack(const float* i) {
+        return make_uint4(__float_as_uint(i[0]), __float_as_uint(i[1]), __float_as_uint(i[2]), __float_as_uint(i[3]));
+    }
+};
+template <typename T> struct PxIO<T, 8> {   // 16-bit, 16 bytes
+    typedef uint4 raw_t;
+    static __device__ __forceinline__ raw_t zero() { return make_uint4(0, 0, 0, 0); }
+    static __device__ __forceinline__ void unpack(const raw_t& v, float* o) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            T lo, hi;
+            lo.v = (uint16_t)(w[i] & 0xffffu);
+            hi.v = (uint16_t)(w[i] >> 16);
+            o[2 * i] = to_float(lo);
+            o[2 * i + 1] = to_float(hi);
+        }
+    }
+    static __device__ __forceinline__ raw_t pack(const float* i) {
+        return make_uint4(pack2<T>(i[0], i[1]), pack2<T>(i[2], i[3]), pack2<T>(i[4], i[5]), pack2<T>(i[6], i[7]));
+    }
+};
+template <typename T> struct PxIO<T, 4> {   // 16-bit, 8 bytes
+    typedef uint2 raw_t;
+    static __device__ __forceinline__ raw_t zero() { return make_uint2(0, 0); }
+    static __device__ __forceinline__ void unpack(const raw_t& v, float* o) {
+        const uint32_t w[2] = {v.x, v.y};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            T lo, hi;
+            lo.v = (uint16_t)(w[i] & 0xffffu);
+            hi.v = (uint16_t)(w[i] >> 16);
+            o[2 * i] = to_float(lo);
+            o[2 * i + 1] = to_float(hi);
+        }
+    }
+    static __device__ __forceinline__ raw_t pack(const float* i) { return make_uint2(pack2<T>(i[0], i[1]), pack2<T>(i[2], i[3])); }
+};
+
+template <typename T, int K> struct VecPx { static constexpr int N = (K <= 3 && sizeof(T) == 2) ? 8 : 4; };
+
+// window = [PAD px of the left lane | own PXL px | PAD px of the right lane]; zero past the row ends
+template <int PXL, int PAD>
+__device__ __forceinline__ void build_window(const float* v, float* win, int lane, bool has_left, bool has_right) {
+#pragma unroll
+    for (int i = 0; i < PAD; ++i) {
+        const float l = __shfl(v[PXL - PAD + i], (lane + 63) & 63, 64);
+        const float r = __shfl(v[i], (lane + 1) & 63, 64);
+        win[i] = has_left ? l : 0.f;
+        win[PAD + PXL + i] = has_right ? r : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < PXL; ++i) win[PAD + i] = v[i];
+}
+
+struct VecGeom {
+    int G, gpw, R, nslabs;   // lanes per row, groups per wave, rows per group, slabs per plane
+};
+
+// wave = (plane, slab); group g of the wave owns rows [slab*gpw*R + g*R, +R) of that plane
+template <typename T, int K, bool FLIP>
+__global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restrict__ x, const float* __restrict__ f,
+                                                               T* __restrict__ y, int C, int H, int W, VecGeom vg,
+                                                               long long nwaves) {
+    constexpr int PAD = K / 2;
+    constexpr int PXL = VecPx<T, K>::N;
+    typedef PxIO<T, PXL> IO;
+    typedef typename IO::raw_t raw_t;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long wunit = (long long)blockIdx.x * DW_WAVES + wave;
+    if (wunit >= nwaves) return;
+    const int slab = (int)(wunit % vg.nslabs);
+    const long long plane = wunit / vg.nslabs;
+    const int c = (int)(plane % C);   // wave-uniform => the taps are scalar loads
+
+    float taps[K * K];
+#pragma unroll
+    for (int e = 0; e < K * K; ++e) taps[e] = f[(long long)c * K * K + (FLIP ? (K * K - 1 - e) : e)];
+
+    const int g = lane / vg.G, gl = lane - g * vg.G;
+    const bool live = g < vg.gpw;                    // lanes past the last full group idle (W does not divide 64*PXL)
+    const int h0 = min(H, (slab * vg.gpw + g) * vg.R);
+    const int h1 = live ? min(H, h0 + vg.R) : h0;
+    const int Wq = W / PXL;
+    const raw_t* xp = reinterpret_cast<const raw_t*>(x + plane * (long long)H * W) + gl;
+    raw_t* yp = reinterpret_cast<raw_t*>(y + plane * (long long)H * W) + gl;
+    const bool has_left = gl > 0, has_right = gl < vg.G - 1;
+
+    float acc[K][PXL];
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int p = 0; p < PXL; ++p) acc[i][p] = 0.f;
+
+    const int hstart = h0 - PAD;
+    const int niter_max = vg.R + 2 * PAD;            // wave-uniform trip count (shuffles need every lane)
+    const int niter = (h1 - h0) + 2 * PAD;
+    auto load_row = [&](int t) -> raw_t {
+        const int hin = hstart + t;
+        return (live && t < niter && hin >= 0 && hin < H) ? xp[(long long)hin * Wq] : IO::zero();
+    };
+    raw_t raw[K];   // software ring: K row loads in flight per lane
+#pragma unroll
+    for (int u = 0; u < K; ++u) raw[u] = load_row(u);
+    for (int base = 0; base < niter_max; base += K) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int t = base + u;
+            const int hin = hstart + t;
+            float v[PXL], win[PXL + 2 * PAD + 1];
+            IO::unpack(raw[u], v);
+            raw[u] = load_row(t + K);
+            build_window<PXL, PAD>(v, win, lane, has_left, has_right);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                // input row t feeds output row (t - i) of the group's chunk; rows outside [0, R) are another
+                // group's (or nobody's) -- a wave-uniform test, so halo rows cost loads but no FMAs
+                if (t - i >= 0 && t - i < vg.R) {
+#pragma unroll
+                    for (int p = 0; p < PXL; ++p) {
+                        float a = acc[(u - i + K) % K][p];
+#pragma unroll
+                        for (int j = 0; j < K; ++j) a = fmaf(taps[i * K + j], win[p + j], a);
+                        acc[(u - i + K) % K][p] = a;
+                    }
+                }
+            }
+            const int hout = hin - PAD;
+            if (t < niter && hout >= h0 && hout < h1) yp[(long long)hout * Wq] = IO::pack(acc[(u + 1) % K]);
+#pragma unroll
+            for (int p = 0; p < PXL; ++p) acc[(u + 1) % K][p] = 0.f;
+        }
+    }
+}
+
+// wgrad: wave = (plane, slab); partial[wave][i][j] = sum_{h in slab, w} dy[h][w-j+PAD] * x[h+i-PAD][w]
+template <typename T, int K>
+__global__ void __launch_bounds__(64 * DW_WAVES) dw_wgrad_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                     float* __restrict__ part_out, int H, int W,
+                                                                     VecGeom vg, long long nwaves) {
+    constexpr int PAD = K / 2;
+    constexpr int PXL = 4;
+    typedef PxIO<T, PXL> IO;
+    typedef typename IO::raw_t raw_t;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long wunit = (long long)blockIdx.x * DW_WAVES + wave;
+    if (wunit >= nwaves) return;
+    const int slab = (int)(wunit % vg.nslabs);
+    const long long plane = wunit / vg.nslabs;
+    const int g = lane / vg.G, gl = lane - g * vg.G;
+    const bool live = g < vg.gpw;
+    const int h0 = min(H, (slab * vg.gpw + g) * vg.R);
+    const int h1 = live ? min(H, h0 + vg.R) : h0;
+    const int Wq = W / PXL;
+    const raw_t* dp = reinterpret_cast<const raw_t*>(dy + plane * (long long)H * W) + gl;
+    const raw_t* xp = reinterpret_cast<const raw_t*>(x + plane * (long long)H * W) + gl;
+    const bool has_left = gl > 0, has_right = gl < vg.G - 1;
+
+    float acc[K * K];
+#pragma unroll
+    for (int e = 0; e < K * K; ++e) acc[e] = 0.f;
+    float xr[K][PXL];   // ring of x rows: slot m mod K holds row h0 - PAD + m
+    auto load_x = [&](int r) -> raw_t { return (live && r >= 0 && r < H) ? xp[(long long)r * Wq] : IO::zero(); };
+    auto load_g = [&](int h) -> raw_t { return (h < h1) ? dp[(long long)h * Wq] : IO::zero(); };
+#pragma unroll
+    for (int m = 0; m < K - 1; ++m) IO::unpack(load_x(h0 - PAD + m), xr[m]);
+#pragma unroll
+    for (int p = 0; p < PXL; ++p) xr[K - 1][p] = 0.f;
+    raw_t rawx[K], rawg[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        rawx[u] = load_x(h0 + u + PAD);
+        rawg[u] = load_g(h0 + u);
+    }
+    for (int base = 0; base < vg.R; base += K) {     // wave-uniform trip count
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int h = h0 + base + u;
+            float gv[PXL], gwin[PXL + 2 * PAD + 1];
+            IO::unpack(rawx[u], xr[(u + K - 1) % K]);   // row h + PAD enters the ring
+            IO::unpack(rawg[u], gv);
+            rawx[u] = load_x(h + K + PAD);
+            rawg[u] = load_g(h + K);
+            build_window<PXL, PAD>(gv, gwin, lane, has_left, has_right);
+            if (base + u < vg.R) {   // wave-uniform: iterations past the chunk only drain the unrolled ring
+#pragma unroll
+                for (int i = 0; i < K; ++i)
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        float a = acc[i * K + j];
+#pragma unroll
+                        for (int p = 0; p < PXL; ++p) a = fmaf(xr[(u + i) % K][p], gwin[p + K - 1 - j], a);
+                        acc[i * K + j] = a;
+                    }
+            }
+        }
+    }
+    float* out = part_out + wunit * (K * K);
+#pragma unroll
+    for (int e = 0; e < K * K; ++e) {
+        const float s = wave_sum(acc[e]);
+        if (lane == 0) out[e] = s;
+    }
+}
+
+// df[c][e] = sum_{n, slab} partial[(n*C + c)*nslabs + slab][e]   (fixed order => deterministic)
+__global__ void __launch_bounds__(256) dw_wgrad_vec_reduce_kernel(const float* __restrict__ part, float* __restrict__ df,
+                                                                  int N, int C, int nslabs, int KK) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)C * KK) return;
+    const int c = (int)(idx / KK), e = (int)(idx - (long long)c * KK);
+    float s = 0.f;
+    for (int n = 0; n < N; ++n)
+        for (int q = 0; q < nslabs; ++q) s += part[(((long long)n * C + c) * nslabs + q) * KK + e];
+    df[idx] = s;
+}
+
+// PXL = pixels per lane the kernel for (dtype, K) uses; ok = the vector path applies
+static bool vec_geom(int64_t H, int64_t W, int esize, int PXL, const void* a, const void* b, VecGeom& vg) {
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b);
+    if (H <= 0 || W <= 0 || W % PXL != 0 || W / PXL > 64 || (bits & 15) != 0) return false;
+    (void)esize;
+    vg.G = (int)(W / PXL);
+    vg.gpw = 64 / vg.G;
+    int64_t R = cdiv(H, vg.gpw);
+    if (R < 4) R = 4;
+    if (R > 32) R = 32;
+    vg.R = (int)R;
+    vg.nslabs = (int)cdiv(H, (int64_t)vg.gpw * vg.R);
+    return true;
+}
+
 // df[c][e] = sum_part part_out[part][c][e]   (fixed order => deterministic)
 __global__ void __launch_bounds__(256) dw_wgrad_reduce_kernel(const float* __restrict__ part_out,
                                                               float* __restrict__ df, int nparts, long long CKK) {
@@ -239,6 +494,23 @@ static int wgrad_parts(int64_t N, int64_t C) {
 template <typename T, bool FLIP>
 static int launch_conv(const char* name, const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H,
                        int64_t W, int K, hipStream_t st) {
+    {
+        VecGeom vg;
+#define OFASR_DWV(KK)                                                                                               \
+    if (vec_geom(H, W, (int)sizeof(T), VecPx<T, KK>::N, x, y, vg)) {                                               \
+        const long long nwaves = (long long)N * C * vg.nslabs;                                                     \
+        hipLaunchKernelGGL((dw_vec_kernel<T, KK, FLIP>), dim3((unsigned)cdiv(nwaves, DW_WAVES)), dim3(64 * DW_WAVES), \
+                           0, st, (const T*)x, f, (T*)y, (int)C, (int)H, (int)W, vg, nwaves);                      \
+        return check_launch(name);                                                                                 \
+    }
+        switch (K) {
+            case 1: OFASR_DWV(1) break;
+            case 3: OFASR_DWV(3) break;
+            case 5: OFASR_DWV(5) break;
+            default: OFASR_DWV(7) break;
+        }
+#undef OFASR_DWV
+    }
     const int rows_per_chunk = H <= 32 ? (int)H : 32;
     const int nchunks = (int)cdiv(H, rows_per_chunk);
 #define OFASR_DW_LAUNCH(KK)                                                                                  \
@@ -288,6 +560,29 @@ static int conv_entry(const char* name, const void* x, const float* f, void* y, 
 template <typename T>
 static int launch_wgrad(const char* name, const void* dy, const void* x, float* df, int64_t N, int64_t C,
                         int64_t H, int64_t W, int K, float* ws, hipStream_t st) {
+    {
+        VecGeom vg;
+        if (vec_geom(H, W, (int)sizeof(T), 4, dy, x, vg)) {
+            const long long nwaves = (long long)N * C * vg.nslabs;
+            const unsigned grid = (unsigned)cdiv(nwaves, DW_WAVES);
+#define OFASR_DWWV(KK)                                                                                              \
+    hipLaunchKernelGGL((dw_wgrad_vec_kernel<T, KK>), dim3(grid), dim3(64 * DW_WAVES), 0, st, (const T*)dy, (const T*)x, \
+                       ws, (int)H, (int)W, vg, nwaves)
+            switch (K) {
+                case 1: OFASR_DWWV(1); break;
+                case 3: OFASR_DWWV(3); break;
+                case 5: OFASR_DWWV(5); break;
+                default: OFASR_DWWV(7); break;
+            }
+#undef OFASR_DWWV
+            int rc0 = check_launch(name);
+            if (rc0) return rc0;
+            const long long CKK0 = (long long)C * K * K;
+            hipLaunchKernelGGL(dw_wgrad_vec_reduce_kernel, dim3((unsigned)cdiv(CKK0, 256)), dim3(256), 0, st, ws, df,
+                               (int)N, (int)C, vg.nslabs, K * K);
+            return check_launch(name);
+        }
+    }
     const int nparts = wgrad_parts(N, C);
     const long long units = (long long)C * nparts;
 #define OFASR_DW_WG(KK)                                                                                        \
@@ -324,10 +619,13 @@ OFASR_EXPORT int ofasr_dwconv_dgrad(const void* dy, const float* f, void* dx, in
 }
 
 OFASR_EXPORT size_t ofasr_dwconv_wgrad_workspace(int64_t N, int64_t C, int64_t H, int64_t W, int K) {
-    (void)H;
-    (void)W;
+    (void)W;  // the bound below holds for every W
     if (N <= 0 || C <= 0 || K <= 0) return 0;
-    return (size_t)wgrad_parts(N, C) * (size_t)C * (size_t)K * (size_t)K * sizeof(float);
+    const size_t strip = (size_t)wgrad_parts(N, C) * (size_t)C * (size_t)K * (size_t)K * sizeof(float);
+    // the vector plan (chosen at launch when W and the pointers allow) keeps one partial per (plane, row chunk)
+    // upper bound on slabs per plane for any W: gpw >= 1 and R >= min(32, H) => nslabs <= ceil(H / 4)
+    const size_t vec = (size_t)N * (size_t)C * (size_t)cdiv(H > 0 ? H : 1, 4) * (size_t)K * (size_t)K * sizeof(float);
+    return strip > vec ? strip : vec;
 }
 
 OFASR_EXPORT int ofasr_dwconv_wgrad(const void* dy, const void* x, float* df, int64_t N, int64_t C, int64_t H,
