@@ -307,8 +307,12 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restri
     const T* xn = x + (long long)n * wv.K * HW;
     T* yn = y + ((long long)n * wv.M + m_base) * HW;
 
+#ifndef EXP_NOX
     stage_x_tile<T, 4, ALIGNED>(Xs, xn, wv.K, HW, 0, p0);
+#endif
+#ifndef EXP_NOW
     stage_w_tile<T, FO_ROWS, WVEC>(Ws, wv, m_base, 0);
+#endif
     __syncthreads();
 
     const int cb = wave;
@@ -342,6 +346,13 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restri
             }
         }
     }
+#ifdef EXP_NOSTORE
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) asm volatile("" ::"v"(acc[t][reg]));
+    if (p0 < 0)
+#endif
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int r = 32 * cb + acc_row(reg, h);

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark of the C-ABI entry points at the bench shapes (N=16, 64x64, 64<->384 channels).
+Times each launch with events on the launch stream; prints achieved algorithmic GB/s.
+usage: python tools/kbench.py [--lib path/to/lib.so] [--dtype bf16|f32] [--reps 50] [--only substr]"""
+import argparse
+import ctypes
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "ofa-for-super-resolution_amd"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=None)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--N", type=int, default=16)
+    ap.add_argument("--S", type=int, default=64)
+    a = ap.parse_args()
+    import torch
+    C = importlib.import_module(PKG + "._C")
+    if a.lib:
+        C.LIB_PATH = os.path.abspath(a.lib)
+    L = C.lib()
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
+    code = {"bf16": 2, "f32": 0, "f16": 1}[a.dtype]
+    es = 2 if a.dtype != "f32" else 4
+    dev = "cuda:0"
+    N, S, mid = a.N, a.S, 384
+    HW = S * S
+    x64 = torch.randn(N, 64, S, S, device=dev).to(dt)
+    xm = torch.randn(N, mid, S, S, device=dev).to(dt)
+    ym = torch.empty_like(xm)
+    y64 = torch.empty_like(x64)
+    w1 = torch.randn(384, 64, 1, 1, device=dev) * 0.1
+    w2 = torch.randn(64, 384, 1, 1, device=dev) * 0.1
+    dw1 = torch.zeros_like(w1)
+    dw2 = torch.zeros_like(w2)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    wsn = ctypes.c_size_t(ws.numel())
+    cases = []
+    act_big = (N * (64 + mid) * HW) * es
+    cases.append(("pwconv_fwd 64->384", act_big + 4 * 64 * mid,
+                  lambda: L.ofasr_pwconv_fwd(P(x64), P(w1), 64, P(ym), N, 64, mid, HW, code, st)))
+    cases.append(("pwconv_fwd 384->64", act_big + 4 * 64 * mid,
+                  lambda: L.ofasr_pwconv_fwd(P(xm), P(w2), 384, P(y64), N, mid, 64, HW, code, st)))
+    cases.append(("pwconv_dgrad 384->64 (of expand)", act_big,
+                  lambda: L.ofasr_pwconv_dgrad(P(xm), P(w1), 64, P(y64), N, 64, mid, HW, code, st)))
+    cases.append(("pwconv_dgrad 64->384 (of project)", act_big,
+                  lambda: L.ofasr_pwconv_dgrad(P(x64), P(w2), 384, P(ym), N, mid, 64, HW, code, st)))
+    cases.append(("pwconv_wgrad expand", act_big,
+                  lambda: L.ofasr_pwconv_wgrad(P(xm), P(x64), P(dw1), 64, N, 64, mid, HW, code, P(ws), wsn, st)))
+    cases.append(("pwconv_wgrad project", act_big,
+                  lambda: L.ofasr_pwconv_wgrad(P(x64), P(xm), P(dw2), 384, N, mid, 64, HW, code, P(ws), wsn, st)))
+    for K in (3, 5, 7):
+        f = torch.randn(mid, 1, K, K, device=dev) * 0.1
+        df = torch.zeros_like(f)
+        b = 2 * N * mid * HW * es
+        cases.append(("dwconv_fwd k%d" % K, b, lambda f=f, K=K: L.ofasr_dwconv_fwd(P(xm), P(f), P(ym), N, mid, S, S, K, code, st)))
+        cases.append(("dwconv_wgrad k%d" % K, b, lambda df=df, K=K: L.ofasr_dwconv_wgrad(P(ym), P(xm), P(df), N, mid, S, S, K, code, P(ws), wsn, st)))
+    sc = torch.ones(4, mid, device=dev)
+    cases.append(("bn_stats mid", N * mid * HW * es, lambda: L.ofasr_bn_stats(P(xm), N, mid, HW, code, P(ws), wsn, st)))
+    cases.append(("bn_act_fwd mid relu6", 2 * N * mid * HW * es,
+                  lambda: L.ofasr_bn_act_fwd(P(xm), None, P(ym), P(sc[0]), P(sc[1]), N, mid, HW, 1, code, st)))
+    dg = torch.zeros(mid, device=dev)
+    cases.append(("bn_act_bwd mid relu6", 5 * N * mid * HW * es,
+                  lambda: L.ofasr_bn_act_bwd(P(ym), P(xm), None, P(ym), None, P(sc[0]), P(sc[1]), P(sc[2]), P(sc[3]),
+                                             P(dg), P(dg), N, mid, HW, 1, 1, code, P(ws), wsn, st)))
+    x256 = torch.randn(N, 256, S, S, device=dev).to(dt)
+    y256 = torch.empty(N, 64, 2 * S, 2 * S, device=dev, dtype=dt)
+    cases.append(("pixel_shuffle 256ch", 2 * x256.numel() * es,
+                  lambda: L.ofasr_pixel_shuffle(P(x256), P(y256), N, 64, S, S, 2, es, st)))
+    for name, nbytes, fn in cases:
+        if a.only and a.only not in name:
+            continue
+        for _ in range(5):
+            rc = fn()
+            assert rc == 0, (name, rc, L.ofasr_last_error_string())
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / a.reps
+        print("%-36s %8.1f us  %8.1f GB/s  (%.1f MB algorithmic)" % (name, us, nbytes / us / 1e3, nbytes / 1e6))
+
+
+if __name__ == "__main__":
+    main()
