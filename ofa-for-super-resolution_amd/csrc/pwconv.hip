@@ -307,12 +307,8 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restri
     const T* xn = x + (long long)n * wv.K * HW;
     T* yn = y + ((long long)n * wv.M + m_base) * HW;
 
-#ifndef EXP_NOX
     stage_x_tile<T, 4, ALIGNED>(Xs, xn, wv.K, HW, 0, p0);
-#endif
-#ifndef EXP_NOW
     stage_w_tile<T, FO_ROWS, WVEC>(Ws, wv, m_base, 0);
-#endif
     __syncthreads();
 
     const int cb = wave;
@@ -346,13 +342,6 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restri
             }
         }
     }
-#ifdef EXP_NOSTORE
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) asm volatile("" ::"v"(acc[t][reg]));
-    if (p0 < 0)
-#endif
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int r = 32 * cb + acc_row(reg, h);
@@ -480,44 +469,59 @@ __device__ __forceinline__ void stage_rows64(char* Lt, const T* __restrict__ bas
     }
 }
 
+// pixels staged per barrier: 4 (16-bit) / 2 (fp32) swizzled [64][64] sub-tiles per operand = 64 KiB of LDS,
+// i.e. 64 KiB of loads in flight per block -- the reduction has almost no arithmetic per byte (one MFMA per
+// 8 KiB), so it only runs at HBM speed if every barrier interval moves a lot of data.
+template <typename T> struct WgStage { static constexpr int SUB = Elem<T>::is16 ? 4 : 2; };
+
 template <typename T, bool ALIGNED>
 __global__ void __launch_bounds__(PW_THREADS) pw_wgrad_kernel(const T* __restrict__ R, const T* __restrict__ S,
                                                               float* __restrict__ part, int MR, int NS, int HW,
-                                                              int chunks_per_img, int total_chunks,
-                                                              int chunks_per_split) {
-    __shared__ __attribute__((aligned(16))) char Rt[64 * Elem<T>::wrow];
-    __shared__ __attribute__((aligned(16))) char St[64 * Elem<T>::wrow];
+                                                              int stages_per_img, int total_stages,
+                                                              int stages_per_split) {
+    constexpr int SUB = WgStage<T>::SUB;
+    constexpr int TB = 64 * Elem<T>::wrow;   // bytes of one [64][64] sub-tile
+    __shared__ __attribute__((aligned(16))) char Rt[SUB * TB];
+    __shared__ __attribute__((aligned(16))) char St[SUB * TB];
     const int r0 = blockIdx.x * 64, s0 = blockIdx.y * 64, z = blockIdx.z;
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int c = lane & 31, h = lane >> 5;
     const int rb = wave & 1, sb = wave >> 1;
     f32x16 acc = zero16();
-    const int q_lo = z * chunks_per_split;
-    const int q_hi = min(total_chunks, q_lo + chunks_per_split);
+    const int q_lo = z * stages_per_split;
+    const int q_hi = min(total_stages, q_lo + stages_per_split);
     for (int q = q_lo; q < q_hi; ++q) {
-        const int n = q / chunks_per_img;
-        const int p0 = (q - n * chunks_per_img) * 64;
-        __syncthreads();
-        stage_rows64<T, ALIGNED>(Rt, R + (long long)n * MR * HW, MR, r0, HW, p0);
-        stage_rows64<T, ALIGNED>(St, S + (long long)n * NS * HW, NS, s0, HW, p0);
-        __syncthreads();
-        if constexpr (Elem<T>::is16) {
+        const int n = q / stages_per_img;
+        const int p0 = (q - n * stages_per_img) * (64 * SUB);
+        if (q > q_lo) __syncthreads();
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const s16x8 af = *reinterpret_cast<const s16x8*>(Rt + wtile_chunk_off<T>(32 * rb + c, 2 * s + h));
-                const s16x8 bf = *reinterpret_cast<const s16x8*>(St + wtile_chunk_off<T>(32 * sb + c, 2 * s + h));
-                acc = Mma16<T>::run(af, bf, acc);
-            }
-        } else {
+        for (int sub = 0; sub < SUB; ++sub) {
+            stage_rows64<T, ALIGNED>(Rt + sub * TB, R + (long long)n * MR * HW, MR, r0, HW, p0 + 64 * sub);
+            stage_rows64<T, ALIGNED>(St + sub * TB, S + (long long)n * NS * HW, NS, s0, HW, p0 + 64 * sub);
+        }
+        __syncthreads();
 #pragma unroll
-            for (int s4 = 0; s4 < 8; ++s4) {
-                const float4 a4 = *reinterpret_cast<const float4*>(Rt + wtile_chunk_off<T>(32 * rb + c, 8 * h + s4));
-                const float4 b4 = *reinterpret_cast<const float4*>(St + wtile_chunk_off<T>(32 * sb + c, 8 * h + s4));
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        for (int sub = 0; sub < SUB; ++sub) {
+            const char* Rs = Rt + sub * TB;
+            const char* Ss = St + sub * TB;
+            if constexpr (Elem<T>::is16) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const s16x8 af = *reinterpret_cast<const s16x8*>(Rs + wtile_chunk_off<T>(32 * rb + c, 2 * s + h));
+                    const s16x8 bf = *reinterpret_cast<const s16x8*>(Ss + wtile_chunk_off<T>(32 * sb + c, 2 * s + h));
+                    acc = Mma16<T>::run(af, bf, acc);
+                }
+            } else {
+#pragma unroll
+                for (int s4 = 0; s4 < 8; ++s4) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(Rs + wtile_chunk_off<T>(32 * rb + c, 8 * h + s4));
+                    const float4 b4 = *reinterpret_cast<const float4*>(Ss + wtile_chunk_off<T>(32 * sb + c, 8 * h + s4));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+                }
             }
         }
     }
@@ -531,35 +535,51 @@ __global__ void __launch_bounds__(PW_THREADS) pw_wgrad_kernel(const T* __restric
     }
 }
 
+// dw[r*sr + s*ss] = sum_z part[z][r][s]: 64 outputs x 4 z-lanes per block, z-lane partial sums combined through
+// LDS in a fixed order (deterministic)
 __global__ void __launch_bounds__(256) pw_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                               int MR, int NS, int nsplit, long long sr, long long ss) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float red[4][64];
     const long long tot = (long long)MR * NS;
-    if (idx >= tot) return;
+    const long long idx = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int zl = threadIdx.x >> 6;
     float a = 0.f;
-    for (int z = 0; z < nsplit; ++z) a += part[(long long)z * tot + idx];
-    const long long r = idx / NS, s = idx - r * NS;
-    dw[r * sr + s * ss] = a;
+    if (idx < tot) {
+        int z = zl;
+        for (; z + 12 < nsplit; z += 16) {   // 4 independent loads in flight
+            const float v0 = part[(long long)z * tot + idx], v1 = part[(long long)(z + 4) * tot + idx];
+            const float v2 = part[(long long)(z + 8) * tot + idx], v3 = part[(long long)(z + 12) * tot + idx];
+            a += (v0 + v1) + (v2 + v3);
+        }
+        for (; z < nsplit; z += 4) a += part[(long long)z * tot + idx];
+    }
+    red[zl][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (zl == 0 && idx < tot) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        const long long r = idx / NS, sx = idx - r * NS;
+        dw[r * sr + sx * ss] = t;
+    }
 }
 
 struct WgradPlan {
-    int chunks_per_img, total_chunks, nsplit, chunks_per_split, MR, NS;
+    int stages_per_img, total_stages, nsplit, stages_per_split, MR, NS;
 };
 
-static WgradPlan wgrad_plan(int64_t N, int64_t Cin, int64_t Cout, int64_t HW) {
+static WgradPlan wgrad_plan(int64_t N, int64_t Cin, int64_t Cout, int64_t HW, int sub) {
     WgradPlan p;
     p.MR = (int)(Cout >= Cin ? Cout : Cin);
     p.NS = (int)(Cout >= Cin ? Cin : Cout);
-    p.chunks_per_img = (int)cdiv(HW, 64);
-    p.total_chunks = (int)(N * p.chunks_per_img);
+    p.stages_per_img = (int)cdiv(HW, 64 * sub);
+    p.total_stages = (int)(N * p.stages_per_img);
     const int64_t tiles = cdiv(p.MR, 64) * cdiv(p.NS, 64);
-    int64_t want = 512 / (tiles > 0 ? tiles : 1);
+    int64_t want = 512 / (tiles > 0 ? tiles : 1);   // ~2 blocks per CU
     if (want < 1) want = 1;
-    if (want > p.total_chunks) want = p.total_chunks;
+    if (want > p.total_stages) want = p.total_stages;
     if (want < 1) want = 1;
-    p.chunks_per_split = (int)cdiv(p.total_chunks, want);
-    if (p.chunks_per_split < 1) p.chunks_per_split = 1;
-    p.nsplit = (int)cdiv(p.total_chunks, p.chunks_per_split);
+    p.stages_per_split = (int)cdiv(p.total_stages, want);
+    if (p.stages_per_split < 1) p.stages_per_split = 1;
+    p.nsplit = (int)cdiv(p.total_stages, p.stages_per_split);
     if (p.nsplit < 1) p.nsplit = 1;
     return p;
 }
@@ -627,7 +647,7 @@ static int check_pw_args(const char* name, const void* a, const void* b, const v
 template <typename T>
 static int launch_wgrad(const char* name, const void* dy, const void* x, float* dw, int64_t ldw, int64_t N, int64_t Cin,
                         int64_t Cout, int64_t HW, float* ws, hipStream_t st) {
-    const WgradPlan p = wgrad_plan(N, Cin, Cout, HW);
+    const WgradPlan p = wgrad_plan(N, Cin, Cout, HW, WgStage<T>::SUB);
     const bool big_is_dy = Cout >= Cin;
     const T* R = (const T*)(big_is_dy ? dy : x);
     const T* S = (const T*)(big_is_dy ? x : dy);
@@ -637,14 +657,14 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
     dim3 grid((unsigned)cdiv(p.MR, 64), (unsigned)cdiv(p.NS, 64), (unsigned)p.nsplit);
     if (al)
         hipLaunchKernelGGL((pw_wgrad_kernel<T, true>), grid, dim3(PW_THREADS), 0, st, R, S, ws, p.MR, p.NS, (int)HW,
-                           p.chunks_per_img, p.total_chunks, p.chunks_per_split);
+                           p.stages_per_img, p.total_stages, p.stages_per_split);
     else
         hipLaunchKernelGGL((pw_wgrad_kernel<T, false>), grid, dim3(PW_THREADS), 0, st, R, S, ws, p.MR, p.NS, (int)HW,
-                           p.chunks_per_img, p.total_chunks, p.chunks_per_split);
+                           p.stages_per_img, p.total_stages, p.stages_per_split);
     int rc = check_launch(name);
     if (rc) return rc;
     const long long tot = (long long)p.MR * p.NS;
-    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, st, ws, dw, p.MR, p.NS,
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(256), 0, st, ws, dw, p.MR, p.NS,
                        p.nsplit, sr, ss);
     return check_launch(name);
 }
@@ -675,8 +695,10 @@ OFASR_EXPORT int ofasr_pwconv_dgrad(const void* dy, const float* w, int64_t ldw,
 
 OFASR_EXPORT size_t ofasr_pwconv_wgrad_workspace(int64_t N, int64_t Cin, int64_t Cout, int64_t HW) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return 0;
-    const WgradPlan p = wgrad_plan(N, Cin, Cout, HW);
-    return (size_t)p.nsplit * (size_t)p.MR * (size_t)p.NS * sizeof(float);
+    // the 16-bit and fp32 kernels stage different pixel counts per barrier: size for the larger plan
+    const WgradPlan p4 = wgrad_plan(N, Cin, Cout, HW, 4), p2 = wgrad_plan(N, Cin, Cout, HW, 2);
+    const int ns = p4.nsplit > p2.nsplit ? p4.nsplit : p2.nsplit;
+    return (size_t)ns * (size_t)p4.MR * (size_t)p4.NS * sizeof(float);
 }
 
 OFASR_EXPORT int ofasr_pwconv_wgrad(const void* dy, const void* x, float* dw, int64_t ldw, int64_t N, int64_t Cin,
