@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
+                                                      "the N>1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-images", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -59,8 +61,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)   # rehearsal: ranks may share a GPU
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -150,12 +156,24 @@ def main():
                             "ms_per_step": round(v["total_ms"] / nprof, 4),
                             "GBps": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["total_ms"] > 0 else None}
                         for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])}
-        name, top = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
+        # group API calls that are ONE kernel launch by the HIP kernel they run; the dominant one is reported
+        groups = {}
+        for k, v in summ.items():
+            sym = kernel_symbol(k)
+            if sym is None:
+                continue
+            g = groups.setdefault(sym, {"launches": 0, "total_ms": 0.0, "bytes": 0.0, "flops": 0.0, "calls": []})
+            for f in ("launches", "total_ms", "bytes", "flops"):
+                g[f] += v[f]
+            g["calls"].append(k)
+        name, top = max(groups.items(), key=lambda kv: kv[1]["total_ms"])
         achieved = top["bytes"] / (top["total_ms"] * 1e-3) / 1e9
-        roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "avg_launch_us": round(top["avg_us"], 2),
-                    "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
+        per_launch = top["bytes"] / top["launches"]
+        roofline = {"kernel": name, "api_calls": sorted(top["calls"]), "bound": "hbm", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": pmc_traffic(name), "avg_launch_us": round(1e3 * top["total_ms"] / top["launches"], 2),
+                    "launches_per_step": top["launches"] / nprof,
+                    "algorithmic_bytes_per_launch": per_launch,
                     "mfma_tflops": round(top["flops"] / (top["total_ms"] * 1e-3) / 1e12, 2),
                     "hip_library_ms_per_step": round(sum(v["total_ms"] for v in summ.values()) / nprof, 3)}
 
@@ -181,6 +199,31 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def kernel_symbol(call):
+    """HIP kernel run by a single-launch API call of the timer table (None for multi-kernel calls)."""
+    if call.startswith("pwconv_fwd_") or call.startswith("pwconv_dgrad_"):
+        k_red = int(call.split("_")[2].split("to")[0])      # reduction width
+        return "pw_fanout_kernel" if k_red <= 64 else "pw_fanin_kernel"
+    if call.startswith("dwconv_fwd_k") or call.startswith("dwconv_dgrad_k"):
+        return "dw_vec_kernel<K=%s>" % call.rsplit("k", 1)[1]
+    return {"pixel_shuffle": "ps_r2_kernel", "pixel_unshuffle": "ps_r2_kernel", "bn_stats": "bn_stats_kernel",
+            "bn_act_fwd": "bn_act_fwd_kernel"}.get(call)
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
+    MI355X_MICROARCH.md prescribes) -- produced by tools/pmc_traffic.py into profiles/pmc_traffic.json."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except Exception:
+        return None
+    base = kernel.split("<")[0]
+    hit = table.get(kernel) or table.get(base)
+    return None if hit is None else hit.get("hbm_bytes_per_launch")
 
 
 def run_cpu_baseline(args, S):

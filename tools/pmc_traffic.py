@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE runs as
+MI355X_MICROARCH.md prescribes) into per-kernel HBM bytes per launch.
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out/fetch -- python3 bench.py ...
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d out/write -- python3 bench.py ...
+    python tools/pmc_traffic.py out/fetch out/write profiles/pmc_traffic.json
+
+Units / corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B/lane) -> doubled;
+WRITE_SIZE is exact for 16 B/lane streaming stores.  Only launches from the steady state (the second half
+of each kernel's dispatches) are averaged.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def counter_rows(d):
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    rows = []
+    for f in files:
+        rows += list(csv.DictReader(open(f)))
+    return rows
+
+
+def per_kernel(rows, counter):
+    acc = collections.defaultdict(list)
+    for r in rows:
+        if r.get("Counter_Name") != counter:
+            continue
+        acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    out = {}
+    for k, v in acc.items():
+        tail = v[len(v) // 2:]
+        out[k] = (sum(tail) / len(tail), len(v))
+    return out
+
+
+def short(name):
+    m = re.search(r"ofasr::([a-z0-9_]+)", name)
+    return m.group(1) if m else name.split("(")[0][:60]
+
+
+def main():
+    fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    fetch = per_kernel(counter_rows(fetch_dir), "FETCH_SIZE")
+    write = per_kernel(counter_rows(write_dir), "WRITE_SIZE")
+    table = {}
+    agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
+    for k in set(fetch) | set(write):
+        f, nf = fetch.get(k, (0.0, 0))
+        w, nw = write.get(k, (0.0, 0))
+        n = max(nf, nw)
+        a = agg[short(k)]
+        a[0] += f * n
+        a[1] += w * n
+        a[2] += n
+    for k, (f, w, n) in agg.items():
+        if n == 0:
+            continue
+        fetch_b = 2.0 * 1024.0 * f / n      # KiB -> B, x2: FETCH_SIZE under-counts wide streaming reads on gfx950
+        write_b = 1024.0 * w / n
+        table[k] = {"launches": n, "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
+                    "hbm_bytes_per_launch": fetch_b + write_b}
+    with open(out, "w") as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+    for k, v in sorted(table.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:25]:
+        print("%-40s launches=%6d  fetch=%8.2f MB  write=%8.2f MB" % (k, v["launches"], v["fetch_bytes_per_launch"] / 1e6,
+                                                                       v["write_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
