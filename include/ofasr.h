@@ -127,7 +127,7 @@ int ofasr_pwconv_wgrad(const void* dy, const void* x, float* dw, int64_t ldw, in
  *   bn_finalize  training=1: batch mean / biased variance from the partials, running stats updated in
  *                place (EMA with `momentum`, unbiased variance); training=0: running stats are used.
  *                Emits mean, invstd, scale = gamma*invstd, shift = beta - mean*scale.
- *   bn_act_fwd   y = act(x*scale + shift (+ residual));  act: 0 none, 1 ReLU6
+ *   bn_act_fwd   y = act((x-mean)*scale + beta (+ residual)), beta = shift + mean*scale;  act: 0 none, 1 ReLU6
  *   bn_act_bwd   dz = dy masked by the open ReLU6 window (recomputed from x); dgamma = sum dz*xhat,
  *                dbeta = sum dz; training=1: dx = scale*(dz - dbeta/M - xhat*dgamma/M), training=0:
  *                dx = scale*dz; dresidual (optional, may be NULL) = dz.
@@ -140,12 +140,68 @@ int ofasr_bn_finalize(const void* workspace, int64_t n_partials, int64_t C, doub
                       const float* beta, float* running_mean, float* running_var, double momentum, double eps,
                       int training, float* mean, float* invstd, float* scale, float* shift, void* stream);
 int ofasr_bn_act_fwd(const void* x, const void* residual, void* y, const float* scale, const float* shift,
-                     int64_t N, int64_t C, int64_t HW, int act, int dtype, void* stream);
+                     const float* mean, int64_t N, int64_t C, int64_t HW, int act, int dtype, void* stream);
 size_t ofasr_bn_act_bwd_workspace(int64_t N, int64_t C);
 int ofasr_bn_act_bwd(const void* dy, const void* x, const void* residual, void* dx, void* dresidual,
                      const float* scale, const float* shift, const float* mean, const float* invstd,
                      float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t HW, int act, int training,
                      int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Composite: one DynamicMBConvLayer (+ identity shortcut) per call  -- DynamicMBConvLayer.forward
+ * (reference ofa/elastic_nn/modules/dynamic_layers.py:70-84) + MobileInvertedResidualBlock.forward
+ * (ofa/imagenet_codebase/networks/proxyless_nets.py:44-51) and their autograd, as ONE host call that
+ * enqueues the kernels above in order (expand 1x1 -> BN+ReLU6 -> kernel transform -> depthwise -> BN+ReLU6 ->
+ * project 1x1 -> BN (+ x)).  Exists to keep the host (Python) cost per block at one FFI call: at the
+ * MB stack's sizes the step is otherwise bound by ~100 Python-side launches per block, not by the GPU.
+ *
+ * act_buf  (activation dtype)  [y1 | a1 | y2 | a2] 4*N*mid*HW elements, then [y3 | out] 2*N*Cout*HW
+ *          y = pre-BN conv outputs, a = activated tensors; `out` is the block output.  Kept for backward.
+ * stat_buf (fp32) per BN i in {expand, depthwise, project}: mean | invstd | scale | shift (4*C_i, C = mid, mid,
+ *          Cout), then the active depthwise filter f [mid*K*K].
+ * bwd: tmp_buf (activation dtype) 2*N*mid*HW + N*Cout*HW elements of scratch; every gradient tensor is
+ *          FULLY written (dense max-size parameter gradients, zeros outside the active slice).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t N, Cin, mid, Cout, H, W;
+    int K;            /* active depthwise kernel size */
+    int ks[4];        /* kernel sizes walked: ks[0] = kmax > ... > ks[chain_len-1] = K (as for ofasr_ktransform_*) */
+    int chain_len;    /* number of valid entries in ks (1 when K == kmax) */
+    int transform;    /* 1: apply mats[s] along the chain (KERNEL_TRANSFORM_MODE set and K < kmax); 0: plain crop */
+    int dtype;        /* ofasr_dtype of the activations */
+    int residual;     /* add x to the output (identity shortcut) */
+    int bn_training[3];
+    double bn_momentum[3];
+    double bn_eps[3];
+    int64_t Cmid_max, Cout_max;      /* row counts of the max-size parameters */
+    int64_t ldw1, ldw2;              /* row strides of the 1x1 weights */
+    const float* w1;                 /* [Cmid_max, ldw1] expand */
+    const float* w2;                 /* [Cout_max, ldw2] project */
+    const float* wdw_max;            /* [Cmid_max, kmax, kmax] */
+    const float* mats[3];
+    const float* gamma[3];
+    const float* beta[3];
+    float* running_mean[3];
+    float* running_var[3];
+    int64_t* num_batches_tracked[3]; /* incremented when bn_training[i] (may be NULL) */
+} ofasr_mbconv_desc;
+
+typedef struct {
+    float* dw1;        /* [Cmid_max, ldw1] */
+    float* dw2;        /* [Cout_max, ldw2] */
+    float* dwdw_max;   /* [Cmid_max, kmax, kmax] */
+    float* dmats[3];   /* gradients of the walked matrices (NULL for the others) */
+    float* dgamma[3];  /* lengths Cmid_max, Cmid_max, Cout_max */
+    float* dbeta[3];
+} ofasr_mbconv_grads;
+
+size_t ofasr_mbconv_workspace(const ofasr_mbconv_desc* d);
+size_t ofasr_mbconv_stat_floats(const ofasr_mbconv_desc* d);
+int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, void* act_buf, float* stat_buf, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, const void* act_buf, const float* stat_buf,
+                     const void* dout, void* dx, void* tmp_buf, const ofasr_mbconv_grads* g, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -53,11 +53,35 @@ SIGNATURES = {
     "ofasr_bn_stats": (_c_int, [_c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_vp, _c_sz, _c_vp]),
     "ofasr_bn_finalize": (_c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_vp,
                                    ctypes.c_double, ctypes.c_double, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
-    "ofasr_bn_act_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp]),
+    "ofasr_bn_act_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int,
+                                  _c_vp]),
     "ofasr_bn_act_bwd_workspace": (_c_sz, [_c_i64, _c_i64]),
     "ofasr_bn_act_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                   _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
+    "ofasr_mbconv_workspace": (_c_sz, [_c_vp]),
+    "ofasr_mbconv_stat_floats": (_c_sz, [_c_vp]),
+    "ofasr_mbconv_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "ofasr_mbconv_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
 }
+
+
+class MBConvDesc(ctypes.Structure):
+    """mirror of ofasr_mbconv_desc (include/ofasr.h) -- field order and types must match the C struct"""
+    _fields_ = [
+        ("N", _c_i64), ("Cin", _c_i64), ("mid", _c_i64), ("Cout", _c_i64), ("H", _c_i64), ("W", _c_i64),
+        ("K", _c_int), ("ks", _c_int * 4), ("chain_len", _c_int), ("transform", _c_int), ("dtype", _c_int),
+        ("residual", _c_int), ("bn_training", _c_int * 3), ("bn_momentum", ctypes.c_double * 3),
+        ("bn_eps", ctypes.c_double * 3), ("Cmid_max", _c_i64), ("Cout_max", _c_i64), ("ldw1", _c_i64),
+        ("ldw2", _c_i64), ("w1", _c_vp), ("w2", _c_vp), ("wdw_max", _c_vp), ("mats", _c_vp * 3),
+        ("gamma", _c_vp * 3), ("beta", _c_vp * 3), ("running_mean", _c_vp * 3), ("running_var", _c_vp * 3),
+        ("num_batches_tracked", _c_vp * 3),
+    ]
+
+
+class MBConvGrads(ctypes.Structure):
+    """mirror of ofasr_mbconv_grads"""
+    _fields_ = [("dw1", _c_vp), ("dw2", _c_vp), ("dwdw_max", _c_vp), ("dmats", _c_vp * 3), ("dgamma", _c_vp * 3),
+                ("dbeta", _c_vp * 3)]
 
 
 class OfasrError(RuntimeError):

@@ -53,11 +53,23 @@ __device__ __forceinline__ uint4 pack16(const float* in) {
     }
 }
 
-// deterministic block reduction of two running sums; result valid in thread 0
-__device__ __forceinline__ void block_reduce2(float& a, float& b) {
-    __shared__ float sa[BN_THREADS / 64], sb[BN_THREADS / 64];
-    a = wave_sum(a);
-    b = wave_sum(b);
+// wave-wide sum of a double (two 32-bit shuffles per step); result valid in every lane
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int lo = __shfl_xor(__double2loint(v), o, 64);
+        const int hi = __shfl_xor(__double2hiint(v), o, 64);
+        v += __hiloint2double(hi, lo);
+    }
+    return v;
+}
+
+// deterministic block reduction of two running sums (fp64: the variance is E[x^2] - mean^2, and the backward
+// coefficients are differences of large sums -- fp32 partial sums cost ~1e-5 relative there); valid in thread 0
+__device__ __forceinline__ void block_reduce2(double& a, double& b) {
+    __shared__ double sa[BN_THREADS / 64], sb[BN_THREADS / 64];
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         sa[w] = a;
@@ -65,7 +77,7 @@ __device__ __forceinline__ void block_reduce2(float& a, float& b) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float ra = 0.f, rb = 0.f;
+        double ra = 0.0, rb = 0.0;
 #pragma unroll
         for (int i = 0; i < BN_THREADS / 64; ++i) {
             ra += sa[i];
@@ -80,10 +92,10 @@ __device__ __forceinline__ void block_reduce2(float& a, float& b) {
 // work split: grid = (C, P); block (c, p) covers images n = p, p+P, ... of channel c.
 // ----------------------------------------------------------------------------------- bn_stats
 template <typename T, bool VEC>
-__global__ void __launch_bounds__(BN_THREADS) bn_stats_kernel(const T* __restrict__ x, float* __restrict__ partial,
+__global__ void __launch_bounds__(BN_THREADS) bn_stats_kernel(const T* __restrict__ x, double* __restrict__ partial,
                                                               int N, int C, int HW, int P) {
     const int c = blockIdx.x, p = blockIdx.y;
-    float s = 0.f, ss = 0.f;
+    double s = 0.0, ss = 0.0;
     for (int n = p; n < N; n += P) {
         const T* xp = x + ((long long)n * C + c) * HW;
         if (VEC) {
@@ -92,17 +104,20 @@ __global__ void __launch_bounds__(BN_THREADS) bn_stats_kernel(const T* __restric
             for (int i = threadIdx.x; i < HW / V; i += BN_THREADS) {
                 float f[8];
                 unpack16<T>(xv[i], f);
+                float s8 = 0.f, q8 = 0.f;   // one vector's worth in fp32, then into the fp64 running sums
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
-                    s += f[j];
-                    ss = fmaf(f[j], f[j], ss);
+                    s8 += f[j];
+                    q8 = fmaf(f[j], f[j], q8);
                 }
+                s += (double)s8;
+                ss += (double)q8;
             }
         } else {
             for (int i = threadIdx.x; i < HW; i += BN_THREADS) {
                 const float v = to_float(xp[i]);
-                s += v;
-                ss = fmaf(v, v, ss);
+                s += (double)v;
+                ss += (double)v * (double)v;
             }
         }
     }
@@ -117,7 +132,7 @@ __global__ void __launch_bounds__(BN_THREADS) bn_stats_kernel(const T* __restric
 // mode 0 (train): mean / biased var from the partials; running stats EMA with the unbiased var.
 // mode 1 (eval) : statistics are the running buffers.
 // outputs (length C): mean, invstd, scale = gamma*invstd, shift = beta - mean*scale
-__global__ void __launch_bounds__(64) bn_finalize_kernel(const float* __restrict__ partial, int P, int C, double M,
+__global__ void __launch_bounds__(64) bn_finalize_kernel(const double* __restrict__ partial, int P, int C, double M,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ running_mean,
                                                          float* __restrict__ running_var, double momentum, double eps,
@@ -130,8 +145,8 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(const float* __restrict
     if (training) {
         double s = 0.0, ss = 0.0;
         for (int p = 0; p < P; ++p) {
-            s += (double)partial[((long long)p * C + c) * 2];
-            ss += (double)partial[((long long)p * C + c) * 2 + 1];
+            s += partial[((long long)p * C + c) * 2];
+            ss += partial[((long long)p * C + c) * 2 + 1];
         }
         mean = s / M;
         var = ss / M - mean * mean;
@@ -158,10 +173,12 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(const float* __restrict
 template <typename T, bool VEC, int ACT, bool RES>
 __global__ void __launch_bounds__(BN_THREADS) bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                                 T* __restrict__ y, const float* __restrict__ scale,
-                                                                const float* __restrict__ shift, int N, int C, int HW,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ mean, int N, int C, int HW,
                                                                 int P) {
     const int c = blockIdx.x, p = blockIdx.y;
-    const float sc = scale[c], sh = shift[c];
+    // centred form (x - mean)*scale + beta: x*scale + shift cancels catastrophically when |mean| >> std
+    const float sc = scale[c], mu = mean[c], sh = fmaf(mu, sc, shift[c]);
     for (int n = p; n < N; n += P) {
         const long long off = ((long long)n * C + c) * HW;
         if (VEC) {
@@ -175,7 +192,7 @@ __global__ void __launch_bounds__(BN_THREADS) bn_act_fwd_kernel(const T* __restr
                 if (RES) unpack16<T>(rv[i], r);
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
-                    float v = fmaf(f[j], sc, sh);
+                    float v = fmaf(f[j] - mu, sc, sh);
                     if (RES) v += r[j];
                     if (ACT == 1) v = fminf(fmaxf(v, 0.f), 6.f);
                     f[j] = v;
@@ -184,7 +201,7 @@ __global__ void __launch_bounds__(BN_THREADS) bn_act_fwd_kernel(const T* __restr
             }
         } else {
             for (int i = threadIdx.x; i < HW; i += BN_THREADS) {
-                float v = fmaf(to_float(x[off + i]), sc, sh);
+                float v = fmaf(to_float(x[off + i]) - mu, sc, sh);
                 if (RES) v += to_float(res[off + i]);
                 if (ACT == 1) v = fminf(fmaxf(v, 0.f), 6.f);
                 y[off + i] = from_float<T>(v);
@@ -203,11 +220,11 @@ __global__ void __launch_bounds__(BN_THREADS) bn_bwd_reduce_kernel(const T* __re
                                                                    const float* __restrict__ shift,
                                                                    const float* __restrict__ mean,
                                                                    const float* __restrict__ invstd,
-                                                                   float* __restrict__ partial, int N, int C, int HW,
+                                                                   double* __restrict__ partial, int N, int C, int HW,
                                                                    int P) {
     const int c = blockIdx.x, p = blockIdx.y;
-    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
-    float s = 0.f, sx = 0.f;
+    const float sc = scale[c], mu = mean[c], is = invstd[c], sh = fmaf(mu, sc, shift[c]);
+    double s = 0.0, sx = 0.0;
     for (int n = p; n < N; n += P) {
         const long long off = ((long long)n * C + c) * HW;
         if (VEC) {
@@ -220,29 +237,32 @@ __global__ void __launch_bounds__(BN_THREADS) bn_bwd_reduce_kernel(const T* __re
                 unpack16<T>(xv[i], f);
                 unpack16<T>(dv[i], g);
                 if (RES) unpack16<T>(rv[i], r);
+                float s8 = 0.f, q8 = 0.f;
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
                     float dz = g[j];
                     if (ACT == 1) {
-                        float pre = fmaf(f[j], sc, sh);
+                        float pre = fmaf(f[j] - mu, sc, sh);
                         if (RES) pre += r[j];
                         dz = (pre > 0.f && pre < 6.f) ? dz : 0.f;
                     }
-                    s += dz;
-                    sx = fmaf(dz, (f[j] - mu) * is, sx);
+                    s8 += dz;
+                    q8 = fmaf(dz, (f[j] - mu) * is, q8);
                 }
+                s += (double)s8;
+                sx += (double)q8;
             }
         } else {
             for (int i = threadIdx.x; i < HW; i += BN_THREADS) {
                 const float xf = to_float(x[off + i]);
                 float dz = to_float(dy[off + i]);
                 if (ACT == 1) {
-                    float pre = fmaf(xf, sc, sh);
+                    float pre = fmaf(xf - mu, sc, sh);
                     if (RES) pre += to_float(res[off + i]);
                     dz = (pre > 0.f && pre < 6.f) ? dz : 0.f;
                 }
-                s += dz;
-                sx = fmaf(dz, (xf - mu) * is, sx);
+                s += (double)dz;
+                sx += (double)dz * (double)((xf - mu) * is);
             }
         }
     }
@@ -254,9 +274,8 @@ __global__ void __launch_bounds__(BN_THREADS) bn_bwd_reduce_kernel(const T* __re
 }
 
 // dgamma[c] = sum dz*xhat, dbeta[c] = sum dz; coefficients of the apply pass:
-//   train: dx = k1*dz + k2*x + k3  with k1 = scale, k2 = -scale*invstd*dgamma/M, k3 = -scale*dbeta/M - k2*mean
-//   eval : dx = scale*dz
-__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __restrict__ partial, int P, int C, double M,
+//   dx = scale * (dz - a - xhat*b),  a = dbeta/M, b = dgamma/M  (a = b = 0 in eval mode)
+__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double* __restrict__ partial, int P, int C, double M,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, int training,
@@ -266,20 +285,14 @@ __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __rest
     if (c >= C) return;
     double s = 0.0, sx = 0.0;
     for (int p = 0; p < P; ++p) {
-        s += (double)partial[((long long)p * C + c) * 2];
-        sx += (double)partial[((long long)p * C + c) * 2 + 1];
+        s += partial[((long long)p * C + c) * 2];
+        sx += partial[((long long)p * C + c) * 2 + 1];
     }
     if (dgamma) dgamma[c] = (float)sx;
     if (dbeta) dbeta[c] = (float)s;
-    const double k1 = (double)scale[c];
-    double k2 = 0.0, k3 = 0.0;
-    if (training) {
-        k2 = -k1 * (double)invstd[c] * sx / M;
-        k3 = -k1 * s / M - k2 * (double)mean[c];
-    }
-    coef[3 * c] = (float)k1;
-    coef[3 * c + 1] = (float)k2;
-    coef[3 * c + 2] = (float)k3;
+    coef[3 * c] = scale[c];
+    coef[3 * c + 1] = training ? (float)(s / M) : 0.f;      // mean of dz
+    coef[3 * c + 2] = training ? (float)(sx / M) : 0.f;     // mean of dz * xhat
 }
 
 // dx = k1*dz + k2*x + k3;  optionally also emits dres = dz (gradient of the residual branch)
@@ -288,11 +301,13 @@ __global__ void __launch_bounds__(BN_THREADS) bn_bwd_apply_kernel(const T* __res
                                                                   const T* __restrict__ res, T* __restrict__ dx,
                                                                   T* __restrict__ dres, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd,
                                                                   const float* __restrict__ coef, int N, int C, int HW,
                                                                   int P) {
     const int c = blockIdx.x, p = blockIdx.y;
-    const float sc = scale[c], sh = shift[c];
-    const float k1 = coef[3 * c], k2 = coef[3 * c + 1], k3 = coef[3 * c + 2];
+    const float sc = scale[c], mu = mean[c], is = invstd[c], sh = fmaf(mu, sc, shift[c]);
+    const float k1 = coef[3 * c], ka = coef[3 * c + 1], kb = coef[3 * c + 2];
     for (int n = p; n < N; n += P) {
         const long long off = ((long long)n * C + c) * HW;
         if (VEC) {
@@ -311,12 +326,12 @@ __global__ void __launch_bounds__(BN_THREADS) bn_bwd_apply_kernel(const T* __res
                 for (int j = 0; j < V; ++j) {
                     float dz = g[j];
                     if (ACT == 1) {
-                        float pre = fmaf(f[j], sc, sh);
+                        float pre = fmaf(f[j] - mu, sc, sh);
                         if (RES) pre += r[j];
                         dz = (pre > 0.f && pre < 6.f) ? dz : 0.f;
                     }
                     g[j] = dz;
-                    o[j] = fmaf(k1, dz, fmaf(k2, f[j], k3));
+                    o[j] = k1 * (dz - ka - (f[j] - mu) * is * kb);
                 }
                 ov[i] = pack16<T>(o);
                 if (orv) orv[i] = pack16<T>(g);
@@ -326,11 +341,11 @@ __global__ void __launch_bounds__(BN_THREADS) bn_bwd_apply_kernel(const T* __res
                 const float xf = to_float(x[off + i]);
                 float dz = to_float(dy[off + i]);
                 if (ACT == 1) {
-                    float pre = fmaf(xf, sc, sh);
+                    float pre = fmaf(xf - mu, sc, sh);
                     if (RES) pre += to_float(res[off + i]);
                     dz = (pre > 0.f && pre < 6.f) ? dz : 0.f;
                 }
-                dx[off + i] = from_float<T>(fmaf(k1, dz, fmaf(k2, xf, k3)));
+                dx[off + i] = from_float<T>(k1 * (dz - ka - (xf - mu) * is * kb));
                 if (RES && dres) dres[off + i] = from_float<T>(dz);
             }
         }
@@ -374,7 +389,7 @@ using namespace ofasr;
 
 OFASR_EXPORT size_t ofasr_bn_workspace(int64_t N, int64_t C) {
     if (N <= 0 || C <= 0) return 0;
-    return (size_t)bn_parts(N, C) * (size_t)C * 2 * sizeof(float);
+    return (size_t)bn_parts(N, C) * (size_t)C * 2 * sizeof(double);
 }
 
 OFASR_EXPORT int ofasr_bn_stats(const void* x, int64_t N, int64_t C, int64_t HW, int dtype, void* workspace,
@@ -390,9 +405,9 @@ OFASR_EXPORT int ofasr_bn_stats(const void* x, int64_t N, int64_t C, int64_t HW,
     const bool v = vec_ok(HW, dtype, x, nullptr, nullptr, nullptr);
     OFASR_BN_DISPATCH_T(dtype, {
         if (v) hipLaunchKernelGGL((bn_stats_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)x,
-                                  (float*)workspace, (int)N, (int)C, (int)HW, P);
+                                  (double*)workspace, (int)N, (int)C, (int)HW, P);
         else hipLaunchKernelGGL((bn_stats_kernel<T, false>), grid, dim3(BN_THREADS), 0, st, (const T*)x,
-                                (float*)workspace, (int)N, (int)C, (int)HW, P);
+                                (double*)workspace, (int)N, (int)C, (int)HW, P);
     });
     return check_launch(name);
 }
@@ -406,7 +421,7 @@ OFASR_EXPORT int ofasr_bn_finalize(const void* workspace, int64_t n_partials, in
     OFASR_REQUIRE(training ? (workspace != nullptr && n_partials > 0 && count > 0) : (running_mean && running_var),
                   OFASR_ERR_INVALID_ARG, "%s: missing statistics source", name);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, as_stream(stream),
-                       (const float*)workspace, (int)n_partials, (int)C, count, gamma, beta, running_mean, running_var,
+                       (const double*)workspace, (int)n_partials, (int)C, count, gamma, beta, running_mean, running_var,
                        momentum, eps, training, mean, invstd, scale, shift);
     return check_launch(name);
 }
@@ -414,11 +429,12 @@ OFASR_EXPORT int ofasr_bn_finalize(const void* workspace, int64_t n_partials, in
 OFASR_EXPORT int ofasr_bn_partials(int64_t N, int64_t C) { return (N > 0 && C > 0) ? bn_parts(N, C) : 0; }
 
 OFASR_EXPORT int ofasr_bn_act_fwd(const void* x, const void* residual, void* y, const float* scale, const float* shift,
-                                  int64_t N, int64_t C, int64_t HW, int act, int dtype, void* stream) {
+                                  const float* mean, int64_t N, int64_t C, int64_t HW, int act, int dtype,
+                                  void* stream) {
     const char* name = "ofasr_bn_act_fwd";
     int rc = check_bn(name, N, C, HW, dtype);
     if (rc) return rc;
-    OFASR_REQUIRE(x && y && scale && shift, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(x && y && scale && shift && mean, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
     OFASR_REQUIRE(act == 0 || act == 1, OFASR_ERR_UNSUPPORTED, "%s: act %d not in {0 none, 1 relu6}", name, act);
     const int P = bn_parts(N, C);
     dim3 grid((unsigned)C, (unsigned)P);
@@ -426,7 +442,7 @@ OFASR_EXPORT int ofasr_bn_act_fwd(const void* x, const void* residual, void* y, 
     const bool v = vec_ok(HW, dtype, x, residual, y, nullptr);
 #define OFASR_BNF(VEC, ACT, RES)                                                                                   \
     hipLaunchKernelGGL((bn_act_fwd_kernel<T, VEC, ACT, RES>), grid, dim3(BN_THREADS), 0, st, (const T*)x,          \
-                       (const T*)residual, (T*)y, scale, shift, (int)N, (int)C, (int)HW, P)
+                       (const T*)residual, (T*)y, scale, shift, mean, (int)N, (int)C, (int)HW, P)
     OFASR_BN_DISPATCH_T(dtype, {
         if (v) {
             if (act == 1) { if (residual) OFASR_BNF(true, 1, true); else OFASR_BNF(true, 1, false); }
@@ -450,11 +466,11 @@ OFASR_EXPORT int ofasr_bn_act_bwd(const void* dy, const void* x, const void* res
     OFASR_REQUIRE(dy && x && dx && scale && shift && mean && invstd, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
     OFASR_REQUIRE(act == 0 || act == 1, OFASR_ERR_UNSUPPORTED, "%s: act %d not in {0 none, 1 relu6}", name, act);
     const int P = bn_parts(N, C);
-    const size_t need = (size_t)P * C * 2 * sizeof(float) + (size_t)C * 3 * sizeof(float);
+    const size_t need = (size_t)P * C * 2 * sizeof(double) + (size_t)C * 3 * sizeof(float);
     OFASR_REQUIRE(workspace && workspace_bytes >= need, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", name,
                   workspace_bytes, need);
-    float* partial = (float*)workspace;
-    float* coef = partial + (size_t)P * C * 2;
+    double* partial = (double*)workspace;
+    float* coef = (float*)(partial + (size_t)P * C * 2);
     dim3 grid((unsigned)C, (unsigned)P);
     hipStream_t st = as_stream(stream);
     const bool v = vec_ok(HW, dtype, dy, x, residual, dx) && ((reinterpret_cast<uintptr_t>(dresidual) & 15) == 0);
@@ -463,8 +479,8 @@ OFASR_EXPORT int ofasr_bn_act_bwd(const void* dy, const void* x, const void* res
                        (const T*)x, (const T*)residual, scale, shift, mean, invstd, partial, (int)N, (int)C, (int)HW, P)
 #define OFASR_BNA(VEC, ACT, RES)                                                                                     \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC, ACT, RES>), grid, dim3(BN_THREADS), 0, st, (const T*)dy,         \
-                       (const T*)x, (const T*)residual, (T*)dx, (T*)dresidual, scale, shift, coef, (int)N, (int)C,   \
-                       (int)HW, P)
+                       (const T*)x, (const T*)residual, (T*)dx, (T*)dresidual, scale, shift, mean, invstd, coef,     \
+                       (int)N, (int)C, (int)HW, P)
 #define OFASR_BN_BOTH(MACRO)                                                                              \
     OFASR_BN_DISPATCH_T(dtype, {                                                                          \
         if (v) {                                                                                          \
@@ -491,5 +507,5 @@ OFASR_EXPORT int ofasr_bn_act_bwd(const void* dy, const void* x, const void* res
 
 OFASR_EXPORT size_t ofasr_bn_act_bwd_workspace(int64_t N, int64_t C) {
     if (N <= 0 || C <= 0) return 0;
-    return (size_t)bn_parts(N, C) * C * 2 * sizeof(float) + (size_t)C * 3 * sizeof(float);
+    return (size_t)bn_parts(N, C) * C * 2 * sizeof(double) + (size_t)C * 3 * sizeof(float);
 }

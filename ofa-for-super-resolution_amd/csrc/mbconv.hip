@@ -1,0 +1,263 @@
+// mbconv.hip -- composite MB-block entry points: one host call enqueues every kernel of a
+// DynamicMBConvLayer (+ identity shortcut) forward or backward (see include/ofasr.h).
+//
+// No new arithmetic lives here: it sequences the kernels of pwconv.hip / dwconv.hip / ktransform.hip /
+// bnact.hip on one stream, carving a caller-provided workspace.  The point is host cost: per block the
+// Python side makes 1 FFI call per direction instead of ~25 (each with its own autograd node, allocations
+// and ctypes marshalling), which is what bounded the training step once the kernels were fast.
+#include "ofasr_common.h"
+
+namespace ofasr {
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct MbSizes {
+    size_t es;            // activation element size
+    size_t mid_elems;     // N*mid*HW
+    size_t out_elems;     // N*Cout*HW
+    size_t ws_bn;         // statistics partials (largest BN)
+    size_t ws_bn_bwd;
+    size_t ws_dw;
+    size_t ws_pw;
+    size_t ws_kt;
+    size_t scratch;       // region shared by whichever kernel is running
+    size_t df_bytes;      // depthwise filter gradient (lives from dw wgrad to the kernel-transform backward)
+    size_t total;
+};
+
+static MbSizes mb_sizes(const ofasr_mbconv_desc* d) {
+    MbSizes s;
+    const int64_t HW = d->H * d->W;
+    s.es = d->dtype == OFASR_F32 ? 4 : 2;
+    s.mid_elems = (size_t)(d->N * d->mid * HW);
+    s.out_elems = (size_t)(d->N * d->Cout * HW);
+    const int64_t cbig = d->mid > d->Cout ? d->mid : d->Cout;
+    s.ws_bn = align_up(ofasr_bn_workspace(d->N, cbig), 256);
+    s.ws_bn_bwd = align_up(ofasr_bn_act_bwd_workspace(d->N, cbig), 256);
+    s.ws_dw = align_up(ofasr_dwconv_wgrad_workspace(d->N, d->mid, d->H, d->W, d->K), 256);
+    size_t pw1 = ofasr_pwconv_wgrad_workspace(d->N, d->Cin, d->mid, HW);
+    size_t pw2 = ofasr_pwconv_wgrad_workspace(d->N, d->mid, d->Cout, HW);
+    s.ws_pw = align_up(pw1 > pw2 ? pw1 : pw2, 256);
+    s.ws_kt = align_up(ofasr_ktransform_bwd_workspace(d->ks, d->chain_len - 1, d->mid), 256);
+    // kernels run back to back on one stream, so the regions are reused: one slab sized for the largest user
+    size_t m = s.ws_bn;
+    if (s.ws_bn_bwd > m) m = s.ws_bn_bwd;
+    if (s.ws_dw > m) m = s.ws_dw;
+    if (s.ws_pw > m) m = s.ws_pw;
+    s.scratch = m;
+    s.df_bytes = align_up((size_t)(d->mid * d->K * d->K) * sizeof(float), 256);
+    s.total = s.scratch + s.df_bytes + s.ws_kt + 256;
+    return s;
+}
+
+static int check_desc(const char* name, const ofasr_mbconv_desc* d) {
+    OFASR_REQUIRE(d != nullptr, OFASR_ERR_INVALID_ARG, "%s: null descriptor", name);
+    OFASR_REQUIRE(d->N > 0 && d->Cin > 0 && d->mid > 0 && d->Cout > 0 && d->H > 0 && d->W > 0, OFASR_ERR_INVALID_ARG,
+                  "%s: bad shape", name);
+    OFASR_REQUIRE(d->chain_len >= 1 && d->chain_len <= 4, OFASR_ERR_INVALID_ARG, "%s: bad kernel chain", name);
+    OFASR_REQUIRE(d->ks[d->chain_len - 1] == d->K, OFASR_ERR_INVALID_ARG, "%s: chain does not end at K", name);
+    OFASR_REQUIRE(d->w1 && d->w2 && d->wdw_max, OFASR_ERR_INVALID_ARG, "%s: null weight", name);
+    OFASR_REQUIRE(!d->residual || d->Cin == d->Cout, OFASR_ERR_INVALID_ARG, "%s: residual needs Cin == Cout", name);
+    for (int i = 0; i < 3; ++i)
+        OFASR_REQUIRE(d->gamma[i] && d->beta[i] && d->running_mean[i] && d->running_var[i], OFASR_ERR_INVALID_ARG,
+                      "%s: null BN tensor %d", name, i);
+    return OFASR_OK;
+}
+
+__global__ void bump_counters_kernel(int64_t* a, int64_t* b, int64_t* c) {
+    if (threadIdx.x == 0) {
+        if (a) *a += 1;
+        if (b) *b += 1;
+        if (c) *c += 1;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) add_inplace_kernel(T* __restrict__ a, const T* __restrict__ b, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        a[i] = from_float<T>(to_float(a[i]) + to_float(b[i]));
+}
+
+struct StatView {
+    float *mean, *invstd, *scale, *shift;
+};
+static StatView stat_view(float* base, int which, int64_t mid, int64_t cout) {
+    const int64_t off[3] = {0, 4 * mid, 8 * mid};
+    const int64_t C = which < 2 ? mid : cout;
+    float* p = base + off[which];
+    return StatView{p, p + C, p + 2 * C, p + 3 * C};
+}
+
+// BatchNorm(+act)(+residual) forward of one of the block's three BNs
+static int bn_forward(const ofasr_mbconv_desc* d, int which, const void* x, const void* res, void* y, int64_t C,
+                      int act, float* stat_buf, void* ws, size_t ws_bytes, void* stream) {
+    const int64_t HW = d->H * d->W;
+    StatView sv = stat_view(stat_buf, which, d->mid, d->Cout);
+    int rc;
+    int64_t np = 0;
+    if (d->bn_training[which]) {
+        rc = ofasr_bn_stats(x, d->N, C, HW, d->dtype, ws, ws_bytes, stream);
+        if (rc) return rc;
+        np = ofasr_bn_partials(d->N, C);
+    }
+    rc = ofasr_bn_finalize(ws, np, C, (double)(d->N * HW), d->gamma[which], d->beta[which], d->running_mean[which],
+                           d->running_var[which], d->bn_momentum[which], d->bn_eps[which], d->bn_training[which],
+                           sv.mean, sv.invstd, sv.scale, sv.shift, stream);
+    if (rc) return rc;
+    return ofasr_bn_act_fwd(x, res, y, sv.scale, sv.shift, sv.mean, d->N, C, HW, act, d->dtype, stream);
+}
+
+}  // namespace ofasr
+
+using namespace ofasr;
+
+OFASR_EXPORT size_t ofasr_mbconv_workspace(const ofasr_mbconv_desc* d) {
+    if (!d || d->N <= 0) return 0;
+    return mb_sizes(d).total;
+}
+
+OFASR_EXPORT size_t ofasr_mbconv_stat_floats(const ofasr_mbconv_desc* d) {
+    if (!d) return 0;
+    return (size_t)(8 * d->mid + 4 * d->Cout + d->mid * d->K * d->K);
+}
+
+OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, void* act_buf, float* stat_buf,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    const char* name = "ofasr_mbconv_fwd";
+    int rc = check_desc(name, d);
+    if (rc) return rc;
+    OFASR_REQUIRE(x && act_buf && stat_buf, OFASR_ERR_INVALID_ARG, "%s: null buffer", name);
+    const MbSizes s = mb_sizes(d);
+    OFASR_REQUIRE(workspace && workspace_bytes >= s.total, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B",
+                  name, workspace_bytes, s.total);
+    const int64_t HW = d->H * d->W;
+    char* a = (char*)act_buf;
+    void* y1 = a;
+    void* a1 = a + s.mid_elems * s.es;
+    void* y2 = a + 2 * s.mid_elems * s.es;
+    void* a2 = a + 3 * s.mid_elems * s.es;
+    void* y3 = a + 4 * s.mid_elems * s.es;
+    void* out = a + (4 * s.mid_elems + s.out_elems) * s.es;
+    float* f = stat_buf + 8 * d->mid + 4 * d->Cout;
+
+    if ((d->bn_training[0] && d->num_batches_tracked[0]) || (d->bn_training[1] && d->num_batches_tracked[1]) ||
+        (d->bn_training[2] && d->num_batches_tracked[2])) {
+        hipLaunchKernelGGL(bump_counters_kernel, dim3(1), dim3(64), 0, as_stream(stream),
+                           d->bn_training[0] ? d->num_batches_tracked[0] : nullptr,
+                           d->bn_training[1] ? d->num_batches_tracked[1] : nullptr,
+                           d->bn_training[2] ? d->num_batches_tracked[2] : nullptr);
+        rc = check_launch(name);
+        if (rc) return rc;
+    }
+    // expand 1x1 -> BN + ReLU6
+    rc = ofasr_pwconv_fwd(x, d->w1, d->ldw1, y1, d->N, d->Cin, d->mid, HW, d->dtype, stream);
+    if (rc) return rc;
+    rc = bn_forward(d, 0, y1, nullptr, a1, d->mid, 1, stat_buf, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    // active depthwise filter -> depthwise -> BN + ReLU6
+    rc = ofasr_ktransform_fwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, f, d->mid,
+                              stream);
+    if (rc) return rc;
+    rc = ofasr_dwconv_fwd(a1, f, y2, d->N, d->mid, d->H, d->W, d->K, d->dtype, stream);
+    if (rc) return rc;
+    rc = bn_forward(d, 1, y2, nullptr, a2, d->mid, 1, stat_buf, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    // project 1x1 -> BN (+ shortcut)
+    rc = ofasr_pwconv_fwd(a2, d->w2, d->ldw2, y3, d->N, d->mid, d->Cout, HW, d->dtype, stream);
+    if (rc) return rc;
+    return bn_forward(d, 2, y3, d->residual ? x : nullptr, out, d->Cout, 0, stat_buf, workspace, workspace_bytes,
+                      stream);
+}
+
+OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, const void* act_buf, const float* stat_buf,
+                                  const void* dout, void* dx, void* tmp_buf, const ofasr_mbconv_grads* g,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    const char* name = "ofasr_mbconv_bwd";
+    int rc = check_desc(name, d);
+    if (rc) return rc;
+    OFASR_REQUIRE(x && act_buf && stat_buf && dout && dx && tmp_buf && g, OFASR_ERR_INVALID_ARG, "%s: null buffer", name);
+    OFASR_REQUIRE(g->dw1 && g->dw2 && g->dwdw_max, OFASR_ERR_INVALID_ARG, "%s: null weight gradient", name);
+    for (int i = 0; i < 3; ++i)
+        OFASR_REQUIRE(g->dgamma[i] && g->dbeta[i], OFASR_ERR_INVALID_ARG, "%s: null BN gradient %d", name, i);
+    const MbSizes s = mb_sizes(d);
+    OFASR_REQUIRE(workspace && workspace_bytes >= s.total, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B",
+                  name, workspace_bytes, s.total);
+    const int64_t HW = d->H * d->W;
+    hipStream_t st = as_stream(stream);
+    const char* a = (const char*)act_buf;
+    const void* y1 = a;
+    const void* a1 = a + s.mid_elems * s.es;
+    const void* y2 = a + 2 * s.mid_elems * s.es;
+    const void* a2 = a + 3 * s.mid_elems * s.es;
+    const void* y3 = a + 4 * s.mid_elems * s.es;
+    char* t = (char*)tmp_buf;
+    void* tA = t;                                    // mid: da2 -> dy2 (in place)
+    void* tB = t + s.mid_elems * s.es;               // mid: da1 -> dy1 (in place)
+    void* t3 = t + 2 * s.mid_elems * s.es;           // Cout: dy3
+    float* sb = const_cast<float*>(stat_buf);
+    const float* f = stat_buf + 8 * d->mid + 4 * d->Cout;
+    const int kmax = d->ks[0];
+
+    // dense parameter gradients: zero everything, the kernels fill the active slices
+    hipError_t e = hipMemsetAsync(g->dw1, 0, (size_t)d->Cmid_max * d->ldw1 * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(g->dw2, 0, (size_t)d->Cout_max * d->ldw2 * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(g->dwdw_max, 0, (size_t)d->Cmid_max * kmax * kmax * sizeof(float), st);
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) {
+        const size_t n = (size_t)(i < 2 ? d->Cmid_max : d->Cout_max) * sizeof(float);
+        e = hipMemsetAsync(g->dgamma[i], 0, n, st);
+        if (e == hipSuccess) e = hipMemsetAsync(g->dbeta[i], 0, n, st);
+    }
+    OFASR_REQUIRE(e == hipSuccess, OFASR_ERR_LAUNCH, "%s: memset failed: %s", name, hipGetErrorString(e));
+
+    // BN3 (+shortcut, no activation): dy3; the shortcut's gradient is dout itself
+    StatView s3 = stat_view(sb, 2, d->mid, d->Cout);
+    rc = ofasr_bn_act_bwd(dout, y3, nullptr, t3, nullptr, s3.scale, s3.shift, s3.mean, s3.invstd, g->dgamma[2],
+                          g->dbeta[2], d->N, d->Cout, HW, 0, d->bn_training[2], d->dtype, workspace, workspace_bytes,
+                          stream);
+    if (rc) return rc;
+    // project 1x1
+    rc = ofasr_pwconv_dgrad(t3, d->w2, d->ldw2, tA, d->N, d->mid, d->Cout, HW, d->dtype, stream);
+    if (rc) return rc;
+    rc = ofasr_pwconv_wgrad(t3, a2, g->dw2, d->ldw2, d->N, d->mid, d->Cout, HW, d->dtype, workspace, workspace_bytes,
+                            stream);
+    if (rc) return rc;
+    // BN2 + ReLU6 (in place: da2 -> dy2)
+    StatView s2 = stat_view(sb, 1, d->mid, d->Cout);
+    rc = ofasr_bn_act_bwd(tA, y2, nullptr, tA, nullptr, s2.scale, s2.shift, s2.mean, s2.invstd, g->dgamma[1],
+                          g->dbeta[1], d->N, d->mid, HW, 1, d->bn_training[1], d->dtype, workspace, workspace_bytes,
+                          stream);
+    if (rc) return rc;
+    // depthwise: input gradient, filter gradient, and the filter's chain back to the max-size weight / matrices
+    rc = ofasr_dwconv_dgrad(tA, f, tB, d->N, d->mid, d->H, d->W, d->K, d->dtype, stream);
+    if (rc) return rc;
+    float* dfp = (float*)((char*)workspace + s.scratch);
+    rc = ofasr_dwconv_wgrad(tA, a1, dfp, d->N, d->mid, d->H, d->W, d->K, d->dtype, workspace, s.scratch, stream);
+    if (rc) return rc;
+    rc = ofasr_ktransform_bwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, dfp,
+                              g->dwdw_max, g->dmats, d->mid, (char*)workspace + s.scratch + s.df_bytes, s.ws_kt + 256,
+                              stream);
+    if (rc) return rc;
+    // BN1 + ReLU6 (in place: da1 -> dy1)
+    StatView s1 = stat_view(sb, 0, d->mid, d->Cout);
+    rc = ofasr_bn_act_bwd(tB, y1, nullptr, tB, nullptr, s1.scale, s1.shift, s1.mean, s1.invstd, g->dgamma[0],
+                          g->dbeta[0], d->N, d->mid, HW, 1, d->bn_training[0], d->dtype, workspace, workspace_bytes,
+                          stream);
+    if (rc) return rc;
+    // expand 1x1
+    rc = ofasr_pwconv_dgrad(tB, d->w1, d->ldw1, dx, d->N, d->Cin, d->mid, HW, d->dtype, stream);
+    if (rc) return rc;
+    rc = ofasr_pwconv_wgrad(tB, x, g->dw1, d->ldw1, d->N, d->Cin, d->mid, HW, d->dtype, workspace, workspace_bytes,
+                            stream);
+    if (rc) return rc;
+    if (d->residual) {   // x also feeds the shortcut: its gradient is dout
+        const long long n = (long long)(d->N * d->Cin * HW);
+        const unsigned grid = (unsigned)(cdiv(n, 256 * 8) < 4096 ? cdiv(n, 256 * 8) : 4096);
+        switch (d->dtype) {
+            case OFASR_F32: hipLaunchKernelGGL((add_inplace_kernel<float>), dim3(grid), dim3(256), 0, st, (float*)dx, (const float*)dout, n); break;
+            case OFASR_F16: hipLaunchKernelGGL((add_inplace_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (f16_t*)dx, (const f16_t*)dout, n); break;
+            default: hipLaunchKernelGGL((add_inplace_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (bf16_t*)dx, (const bf16_t*)dout, n); break;
+        }
+        rc = check_launch(name);
+    }
+    return rc;
+}

@@ -71,6 +71,10 @@ class DynamicMBConvLayer(MyModule):
         self.depth_conv.conv.active_kernel_size = self.active_kernel_size
         self.point_linear.conv.active_out_channel = self.active_out_channel
         fused = ops.FUSED_BN and self.act_func == "relu6" and not DynamicBatchNorm2d.SET_RUNNING_STATISTICS
+        if (fused and ops.FUSED_BLOCK and self.inverted_bottleneck is not None and x.is_cuda and self.stride == 1
+                and all(m.bn.momentum is not None for m in (self.inverted_bottleneck.bn, self.depth_conv.bn,
+                                                            self.point_linear.bn))):
+            return self._forward_composite(x, residual)
         if not fused:
             if self.inverted_bottleneck is not None:
                 x = self.inverted_bottleneck(x)
@@ -81,6 +85,24 @@ class DynamicMBConvLayer(MyModule):
             x = ops.bn_act(self.inverted_bottleneck.conv(x), self.inverted_bottleneck.bn.bn, ops.ACT_RELU6)
         x = ops.bn_act(self.depth_conv.conv(x), self.depth_conv.bn.bn, ops.ACT_RELU6)
         return ops.bn_act(self.point_linear.conv(x), self.point_linear.bn.bn, ops.ACT_NONE, residual)
+
+    def _forward_composite(self, x, residual):
+        """the whole block (+ shortcut when `residual is x`) as one composite HIP call (ops.FusedMBConvFn)."""
+        dw = self.depth_conv.conv
+        K = self.active_kernel_size
+        chain = dw._chain(K)
+        transform = dw.KERNEL_TRANSFORM_MODE is not None and K < max(dw.kernel_size_list)
+        mats = [getattr(dw, "%dto%d_matrix" % (a, b)) for a, b in zip(chain[:-1], chain[1:])] if transform else []
+        add_x = residual is not None and residual is x
+        bn1, bn2, bn3 = self.inverted_bottleneck.bn.bn, self.depth_conv.bn.bn, self.point_linear.bn.bn
+        cfg = {"mid": self.active_middle_channel(x.size(1)), "out": self.active_out_channel, "K": K, "chain": chain,
+               "residual": add_x, "bns": (bn1, bn2, bn3)}
+        y = ops.FusedMBConvFn.apply(x, cfg, self.inverted_bottleneck.conv.conv.weight, bn1.weight, bn1.bias,
+                                    dw.conv.weight, bn2.weight, bn2.bias, self.point_linear.conv.conv.weight,
+                                    bn3.weight, bn3.bias, *mats)
+        if residual is not None and not add_x:
+            y = y + residual
+        return y
 
     @property
     def module_str(self):

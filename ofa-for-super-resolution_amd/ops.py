@@ -348,8 +348,8 @@ class BNActFn(Function):
         y = torch.empty_like(x)
         rp = _p(residual) if residual is not None else ctypes.c_void_p(None)
         with _timed("bn_act_fwd", (2 + (residual is not None)) * x.numel() * x.element_size()):
-            _C.check(L.ofasr_bn_act_fwd(_p(x), rp, _p(y), _p(scale), _p(shift), N, C, HW, act, _dt(x), _stream()),
-                     "bn_act_fwd")
+            _C.check(L.ofasr_bn_act_fwd(_p(x), rp, _p(y), _p(scale), _p(shift), _p(mean), N, C, HW, act, _dt(x),
+                                        _stream()), "bn_act_fwd")
         keep_res = residual if (residual is not None and act != ACT_NONE) else None
         ctx.save_for_backward(x, stats, keep_res)
         ctx.meta = (bool(training), act, residual is not None, tuple(weight.shape))
@@ -391,3 +391,94 @@ def bn_act(x, bn, act=ACT_NONE, residual=None):
         factor = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
     return BNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, factor, bn.eps, act,
                          residual)
+
+
+# ------------------------------------------------------------------------------ fused MB block
+FUSED_BLOCK = True   # DynamicMBConvLayer (+ shortcut) through ONE composite FFI call per direction
+
+
+class FusedMBConvFn(Function):
+    """DynamicMBConvLayer.forward (+ identity shortcut) as ONE host call per direction (ofasr_mbconv_fwd/_bwd,
+    include/ofasr.h): expand 1x1 -> BN+ReLU6 -> kernel transform -> depthwise -> BN+ReLU6 -> project 1x1 -> BN (+x).
+    Same kernels as the per-op Functions above; what changes is the host cost (1 autograd node and 1 FFI call
+    instead of 7 nodes / ~25 calls per block), which bounds the training step at the MB stack's sizes.
+
+    apply(x, cfg, w1, g1, b1, wdw, g2, b2, w2, g3, b3, *mats); cfg = dict built by DynamicMBConvLayer.forward."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, w1, g1, b1, wdw, g2, b2, w2, g3, b3, *mats):
+        _gpu(x, w1, wdw, w2)
+        x = x.contiguous()
+        L = _C.lib()
+        N, Cin, H, W = x.shape
+        mid, Cout, K, chain = cfg["mid"], cfg["out"], cfg["K"], cfg["chain"]
+        d = _C.MBConvDesc()
+        d.N, d.Cin, d.mid, d.Cout, d.H, d.W = N, Cin, mid, Cout, H, W
+        d.K = K
+        for i, k in enumerate(chain):
+            d.ks[i] = k
+        d.chain_len = len(chain)
+        d.transform = 1 if mats else 0
+        d.dtype = _dt(x)
+        d.residual = 1 if cfg["residual"] else 0
+        bns = cfg["bns"]
+        gam, bet = (g1, g2, g3), (b1, b2, b3)
+        for i, bn in enumerate(bns):
+            training = bn.training or not bn.track_running_stats
+            d.bn_training[i] = 1 if training else 0
+            upd = bn.training and bn.track_running_stats
+            d.bn_momentum[i] = float(bn.momentum) if upd else 0.0
+            d.bn_eps[i] = float(bn.eps)
+            d.gamma[i] = gam[i].data_ptr()
+            d.beta[i] = bet[i].data_ptr()
+            d.running_mean[i] = bn.running_mean.data_ptr()
+            d.running_var[i] = bn.running_var.data_ptr()
+            d.num_batches_tracked[i] = bn.num_batches_tracked.data_ptr() if (upd and bn.num_batches_tracked is not None) else None
+        d.Cmid_max, d.Cout_max = w1.shape[0], w2.shape[0]
+        d.ldw1, d.ldw2 = w1.shape[1], w2.shape[1]
+        d.w1, d.w2, d.wdw_max = w1.data_ptr(), w2.data_ptr(), wdw.data_ptr()
+        for i, m in enumerate(mats):
+            d.mats[i] = m.data_ptr()
+        dp = ctypes.byref(d)
+        HW = H * W
+        act = torch.empty(N * HW * (4 * mid + 2 * Cout), dtype=x.dtype, device=x.device)
+        stat = torch.empty(L.ofasr_mbconv_stat_floats(dp), dtype=torch.float32, device=x.device)
+        wsn = L.ofasr_mbconv_workspace(dp)
+        ws = torch.empty(wsn, dtype=torch.uint8, device=x.device)
+        with _timed("mbconv_fwd"):
+            _C.check(L.ofasr_mbconv_fwd(dp, _p(x), _p(act), _p(stat), _p(ws), wsn, _stream()), "mbconv_fwd")
+        ctx.save_for_backward(x, act, stat, w1, wdw, w2, g1, g2, g3, *mats)
+        ctx.desc = d
+        ctx.keep = (bns, ws)       # keeps the BN buffers the descriptor points at alive; workspace reused in backward
+        return act[N * HW * (4 * mid + Cout):].view(N, Cout, H, W)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x, act, stat, w1, wdw, w2, g1, g2, g3, *mats = ctx.saved_tensors
+        d = ctx.desc
+        bns, ws = ctx.keep
+        L = _C.lib()
+        N, Cin, H, W = x.shape
+        HW = H * W
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        tmp = torch.empty(N * HW * (2 * d.mid + d.Cout), dtype=x.dtype, device=x.device)
+        sizes = [w1.numel(), w2.numel(), wdw.numel()] + [m.numel() for m in mats] + [g1.numel()] * 2 + [g2.numel()] * 2 \
+            + [g3.numel()] * 2
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=x.device)
+        parts = flat.split(sizes)
+        dw1, dw2, dwdw = parts[0].view_as(w1), parts[1].view_as(w2), parts[2].view_as(wdw)
+        nm = len(mats)
+        dmats = [parts[3 + i].view_as(mats[i]) for i in range(nm)]
+        dg1, db1, dg2, db2, dg3, db3 = parts[3 + nm:]
+        g = _C.MBConvGrads()
+        g.dw1, g.dw2, g.dwdw_max = dw1.data_ptr(), dw2.data_ptr(), dwdw.data_ptr()
+        for i, m in enumerate(dmats):
+            g.dmats[i] = m.data_ptr()
+        for i, (a, b) in enumerate(((dg1, db1), (dg2, db2), (dg3, db3))):
+            g.dgamma[i], g.dbeta[i] = a.data_ptr(), b.data_ptr()
+        with _timed("mbconv_bwd"):
+            _C.check(L.ofasr_mbconv_bwd(ctypes.byref(d), _p(x), _p(act), _p(stat), _p(dout), _p(dx), _p(tmp),
+                                        ctypes.byref(g), _p(ws), ws.numel(), _stream()), "mbconv_bwd")
+        return (dx, None, dw1, dg1, db1, dwdw, dg2, db2, dw2, dg3, db3) + tuple(dmats)

@@ -164,6 +164,10 @@ DW_SHAPES = [
     (3, 5, 1, 1),       # degenerate
     (1, 4, 7, 64),
     (1, 3, 70, 65),
+    (2, 6, 12, 8),      # 2 lanes per row, 32 row groups per wave (X4 encoder resolution)
+    (1, 4, 6, 4),       # 1 lane per row
+    (2, 3, 5, 16),
+    (1, 2, 40, 24),
 ]
 
 

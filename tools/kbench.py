@@ -68,7 +68,7 @@ def main():
     sc = torch.ones(4, mid, device=dev)
     cases.append(("bn_stats mid", N * mid * HW * es, lambda: L.ofasr_bn_stats(P(xm), N, mid, HW, code, P(ws), wsn, st)))
     cases.append(("bn_act_fwd mid relu6", 2 * N * mid * HW * es,
-                  lambda: L.ofasr_bn_act_fwd(P(xm), None, P(ym), P(sc[0]), P(sc[1]), N, mid, HW, 1, code, st)))
+                  lambda: L.ofasr_bn_act_fwd(P(xm), None, P(ym), P(sc[0]), P(sc[1]), P(sc[2]), N, mid, HW, 1, code, st)))
     dg = torch.zeros(mid, device=dev)
     cases.append(("bn_act_bwd mid relu6", 5 * N * mid * HW * es,
                   lambda: L.ofasr_bn_act_bwd(P(ym), P(xm), None, P(ym), None, P(sc[0]), P(sc[1]), P(sc[2]), P(sc[3]),
