@@ -213,8 +213,7 @@ def kernel_symbol(call):
         return "pw_fanout_kernel" if k_red <= 64 else "pw_fanin_kernel"
     if call.startswith("dwconv_fwd_k") or call.startswith("dwconv_dgrad_k"):
         return "dw_vec_kernel<K=%s>" % call.rsplit("k", 1)[1]
-    return {"pixel_shuffle": "ps_r2_kernel", "pixel_unshuffle": "ps_r2_kernel", "bn_stats": "bn_stats_kernel",
-            "bn_act_fwd": "bn_act_fwd_kernel"}.get(call)
+    return {"pixel_shuffle": "ps_r2_kernel", "pixel_unshuffle": "ps_r2_kernel"}.get(call)
 
 
 def pmc_traffic(kernel):

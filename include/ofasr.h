@@ -141,6 +141,12 @@ int ofasr_bn_finalize(const void* workspace, int64_t n_partials, int64_t C, doub
                       int training, float* mean, float* invstd, float* scale, float* shift, void* stream);
 int ofasr_bn_act_fwd(const void* x, const void* residual, void* y, const float* scale, const float* shift,
                      const float* mean, int64_t N, int64_t C, int64_t HW, int act, int dtype, void* stream);
+/* statistics pass (training only) + apply pass that folds the finalize in: `stats` [4*C] receives
+ * mean | invstd | scale | shift (kept for backward); workspace >= ofasr_bn_workspace(N, C). */
+int ofasr_bn_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                 float* running_mean, float* running_var, double momentum, double eps, int training, float* stats,
+                 int64_t N, int64_t C, int64_t HW, int act, int dtype, void* workspace, size_t workspace_bytes,
+                 void* stream);
 size_t ofasr_bn_act_bwd_workspace(int64_t N, int64_t C);
 int ofasr_bn_act_bwd(const void* dy, const void* x, const void* residual, void* dx, void* dresidual,
                      const float* scale, const float* shift, const float* mean, const float* invstd,

@@ -55,6 +55,8 @@ SIGNATURES = {
                                    ctypes.c_double, ctypes.c_double, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
     "ofasr_bn_act_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int,
                                   _c_vp]),
+    "ofasr_bn_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_double, ctypes.c_double, _c_int,
+                              _c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
     "ofasr_bn_act_bwd_workspace": (_c_sz, [_c_i64, _c_i64]),
     "ofasr_bn_act_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                   _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),

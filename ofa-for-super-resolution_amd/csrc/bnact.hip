@@ -170,15 +170,65 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(const double* __restric
 
 // --------------------------------------------------------------------------------- bn_act_fwd
 // y = act(x*scale[c] + shift[c] (+ res));  act: 0 none, 1 relu6.   grid = (C, N-chunks)
+// where the per-channel statistics of a forward apply pass come from
+struct BnSource {
+    int mode;                 // 0: given (scale, shift, mean);  1: train, from stats partials;  2: eval, running stats
+    const double* partial;    // mode 1: [Pstat][C][2]
+    int Pstat;
+    double M, momentum, eps;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    float* mean;              // mode 1/2: outputs (written by the p == 0 block of each channel); mode 0: inputs
+    float* invstd;
+    float* scale;
+    float* shift;
+};
+
 template <typename T, bool VEC, int ACT, bool RES>
 __global__ void __launch_bounds__(BN_THREADS) bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
-                                                                T* __restrict__ y, const float* __restrict__ scale,
-                                                                const float* __restrict__ shift,
-                                                                const float* __restrict__ mean, int N, int C, int HW,
+                                                                T* __restrict__ y, BnSource src, int N, int C, int HW,
                                                                 int P) {
     const int c = blockIdx.x, p = blockIdx.y;
-    // centred form (x - mean)*scale + beta: x*scale + shift cancels catastrophically when |mean| >> std
-    const float sc = scale[c], mu = mean[c], sh = fmaf(mu, sc, shift[c]);
+    float sc, mu, sh;   // centred form (x - mean)*scale + beta: x*scale + shift cancels when |mean| >> std
+    if (src.mode == 0) {
+        sc = src.scale[c];
+        mu = src.mean[c];
+        sh = fmaf(mu, sc, src.shift[c]);
+    } else {
+        // every block folds the (tiny) finalize into itself: no separate launch between the passes
+        double mean, var;
+        if (src.mode == 1) {
+            double s = 0.0, ss = 0.0;
+            for (int q = 0; q < src.Pstat; ++q) {
+                s += src.partial[((long long)q * C + c) * 2];
+                ss += src.partial[((long long)q * C + c) * 2 + 1];
+            }
+            mean = s / src.M;
+            var = ss / src.M - mean * mean;
+            if (var < 0.0) var = 0.0;
+        } else {
+            mean = (double)src.running_mean[c];
+            var = (double)src.running_var[c];
+        }
+        const double invstd = 1.0 / sqrt(var + src.eps);
+        const double g = src.gamma ? (double)src.gamma[c] : 1.0, b = src.beta ? (double)src.beta[c] : 0.0;
+        sc = (float)(g * invstd);
+        mu = (float)mean;
+        sh = (float)b;
+        if (p == 0 && threadIdx.x == 0) {
+            src.mean[c] = (float)mean;
+            src.invstd[c] = (float)invstd;
+            src.scale[c] = sc;
+            src.shift[c] = (float)(b - mean * g * invstd);
+            if (src.mode == 1 && src.running_mean) {
+                const double unb = src.M > 1.0 ? var * src.M / (src.M - 1.0) : var;
+                src.running_mean[c] = (float)((1.0 - src.momentum) * (double)src.running_mean[c] + src.momentum * mean);
+                src.running_var[c] = (float)((1.0 - src.momentum) * (double)src.running_var[c] + src.momentum * unb);
+            }
+        }
+    }
     for (int n = p; n < N; n += P) {
         const long long off = ((long long)n * C + c) * HW;
         if (VEC) {
@@ -273,29 +323,8 @@ __global__ void __launch_bounds__(BN_THREADS) bn_bwd_reduce_kernel(const T* __re
     }
 }
 
-// dgamma[c] = sum dz*xhat, dbeta[c] = sum dz; coefficients of the apply pass:
-//   dx = scale * (dz - a - xhat*b),  a = dbeta/M, b = dgamma/M  (a = b = 0 in eval mode)
-__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double* __restrict__ partial, int P, int C, double M,
-                                                             const float* __restrict__ scale,
-                                                             const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd, int training,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             float* __restrict__ coef) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, sx = 0.0;
-    for (int p = 0; p < P; ++p) {
-        s += partial[((long long)p * C + c) * 2];
-        sx += partial[((long long)p * C + c) * 2 + 1];
-    }
-    if (dgamma) dgamma[c] = (float)sx;
-    if (dbeta) dbeta[c] = (float)s;
-    coef[3 * c] = scale[c];
-    coef[3 * c + 1] = training ? (float)(s / M) : 0.f;      // mean of dz
-    coef[3 * c + 2] = training ? (float)(sx / M) : 0.f;     // mean of dz * xhat
-}
-
-// dx = k1*dz + k2*x + k3;  optionally also emits dres = dz (gradient of the residual branch)
+// dx = scale * (dz - a - xhat*b), a = mean(dz), b = mean(dz*xhat) folded from the reduction partials by every block
+// (a = b = 0 in eval mode); the p == 0 block of each channel also writes dgamma / dbeta.  Optionally dres = dz.
 template <typename T, bool VEC, int ACT, bool RES>
 __global__ void __launch_bounds__(BN_THREADS) bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                   const T* __restrict__ res, T* __restrict__ dx,
@@ -303,11 +332,22 @@ __global__ void __launch_bounds__(BN_THREADS) bn_bwd_apply_kernel(const T* __res
                                                                   const float* __restrict__ shift,
                                                                   const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd,
-                                                                  const float* __restrict__ coef, int N, int C, int HW,
+                                                                  const double* __restrict__ partial, int Pred, double M,
+                                                                  int training, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, int N, int C, int HW,
                                                                   int P) {
     const int c = blockIdx.x, p = blockIdx.y;
     const float sc = scale[c], mu = mean[c], is = invstd[c], sh = fmaf(mu, sc, shift[c]);
-    const float k1 = coef[3 * c], ka = coef[3 * c + 1], kb = coef[3 * c + 2];
+    double s = 0.0, sx = 0.0;
+    for (int q = 0; q < Pred; ++q) {
+        s += partial[((long long)q * C + c) * 2];
+        sx += partial[((long long)q * C + c) * 2 + 1];
+    }
+    if (p == 0 && threadIdx.x == 0) {
+        if (dgamma) dgamma[c] = (float)sx;
+        if (dbeta) dbeta[c] = (float)s;
+    }
+    const float k1 = sc, ka = training ? (float)(s / M) : 0.f, kb = training ? (float)(sx / M) : 0.f;
     for (int n = p; n < N; n += P) {
         const long long off = ((long long)n * C + c) * HW;
         if (VEC) {
@@ -428,21 +468,15 @@ OFASR_EXPORT int ofasr_bn_finalize(const void* workspace, int64_t n_partials, in
 
 OFASR_EXPORT int ofasr_bn_partials(int64_t N, int64_t C) { return (N > 0 && C > 0) ? bn_parts(N, C) : 0; }
 
-OFASR_EXPORT int ofasr_bn_act_fwd(const void* x, const void* residual, void* y, const float* scale, const float* shift,
-                                  const float* mean, int64_t N, int64_t C, int64_t HW, int act, int dtype,
-                                  void* stream) {
-    const char* name = "ofasr_bn_act_fwd";
-    int rc = check_bn(name, N, C, HW, dtype);
-    if (rc) return rc;
-    OFASR_REQUIRE(x && y && scale && shift && mean, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
-    OFASR_REQUIRE(act == 0 || act == 1, OFASR_ERR_UNSUPPORTED, "%s: act %d not in {0 none, 1 relu6}", name, act);
+static int launch_bn_apply(const char* name, const void* x, const void* residual, void* y, const BnSource& src,
+                           int64_t N, int64_t C, int64_t HW, int act, int dtype, void* stream) {
     const int P = bn_parts(N, C);
     dim3 grid((unsigned)C, (unsigned)P);
     hipStream_t st = as_stream(stream);
     const bool v = vec_ok(HW, dtype, x, residual, y, nullptr);
 #define OFASR_BNF(VEC, ACT, RES)                                                                                   \
     hipLaunchKernelGGL((bn_act_fwd_kernel<T, VEC, ACT, RES>), grid, dim3(BN_THREADS), 0, st, (const T*)x,          \
-                       (const T*)residual, (T*)y, scale, shift, mean, (int)N, (int)C, (int)HW, P)
+                       (const T*)residual, (T*)y, src, (int)N, (int)C, (int)HW, P)
     OFASR_BN_DISPATCH_T(dtype, {
         if (v) {
             if (act == 1) { if (residual) OFASR_BNF(true, 1, true); else OFASR_BNF(true, 1, false); }
@@ -456,6 +490,56 @@ OFASR_EXPORT int ofasr_bn_act_fwd(const void* x, const void* residual, void* y, 
     return check_launch(name);
 }
 
+OFASR_EXPORT int ofasr_bn_act_fwd(const void* x, const void* residual, void* y, const float* scale, const float* shift,
+                                  const float* mean, int64_t N, int64_t C, int64_t HW, int act, int dtype,
+                                  void* stream) {
+    const char* name = "ofasr_bn_act_fwd";
+    int rc = check_bn(name, N, C, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(x && y && scale && shift && mean, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(act == 0 || act == 1, OFASR_ERR_UNSUPPORTED, "%s: act %d not in {0 none, 1 relu6}", name, act);
+    BnSource src{};
+    src.mode = 0;
+    src.scale = const_cast<float*>(scale);
+    src.shift = const_cast<float*>(shift);
+    src.mean = const_cast<float*>(mean);
+    return launch_bn_apply(name, x, residual, y, src, N, C, HW, act, dtype, stream);
+}
+
+// statistics pass (training) + apply pass with the finalize folded in: 2 launches (1 in eval mode)
+OFASR_EXPORT int ofasr_bn_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, double momentum, double eps, int training,
+                              float* stats, int64_t N, int64_t C, int64_t HW, int act, int dtype, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    const char* name = "ofasr_bn_fwd";
+    int rc = check_bn(name, N, C, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(x && y && stats, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(act == 0 || act == 1, OFASR_ERR_UNSUPPORTED, "%s: act %d not in {0 none, 1 relu6}", name, act);
+    OFASR_REQUIRE(training || (running_mean && running_var), OFASR_ERR_INVALID_ARG, "%s: eval mode needs running stats",
+                  name);
+    BnSource src{};
+    src.mode = training ? 1 : 2;
+    src.M = (double)N * (double)HW;
+    src.momentum = momentum;
+    src.eps = eps;
+    src.gamma = gamma;
+    src.beta = beta;
+    src.running_mean = running_mean;
+    src.running_var = running_var;
+    src.mean = stats;
+    src.invstd = stats + C;
+    src.scale = stats + 2 * C;
+    src.shift = stats + 3 * C;
+    if (training) {
+        rc = ofasr_bn_stats(x, N, C, HW, dtype, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        src.partial = (const double*)workspace;
+        src.Pstat = bn_parts(N, C);
+    }
+    return launch_bn_apply(name, x, residual, y, src, N, C, HW, act, dtype, stream);
+}
+
 OFASR_EXPORT int ofasr_bn_act_bwd(const void* dy, const void* x, const void* residual, void* dx, void* dresidual,
                                   const float* scale, const float* shift, const float* mean, const float* invstd,
                                   float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t HW, int act, int training,
@@ -466,11 +550,11 @@ OFASR_EXPORT int ofasr_bn_act_bwd(const void* dy, const void* x, const void* res
     OFASR_REQUIRE(dy && x && dx && scale && shift && mean && invstd, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
     OFASR_REQUIRE(act == 0 || act == 1, OFASR_ERR_UNSUPPORTED, "%s: act %d not in {0 none, 1 relu6}", name, act);
     const int P = bn_parts(N, C);
-    const size_t need = (size_t)P * C * 2 * sizeof(double) + (size_t)C * 3 * sizeof(float);
+    const size_t need = (size_t)P * C * 2 * sizeof(double);
     OFASR_REQUIRE(workspace && workspace_bytes >= need, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", name,
                   workspace_bytes, need);
     double* partial = (double*)workspace;
-    float* coef = (float*)(partial + (size_t)P * C * 2);
+    const double M = (double)N * (double)HW;
     dim3 grid((unsigned)C, (unsigned)P);
     hipStream_t st = as_stream(stream);
     const bool v = vec_ok(HW, dtype, dy, x, residual, dx) && ((reinterpret_cast<uintptr_t>(dresidual) & 15) == 0);
@@ -479,8 +563,8 @@ OFASR_EXPORT int ofasr_bn_act_bwd(const void* dy, const void* x, const void* res
                        (const T*)x, (const T*)residual, scale, shift, mean, invstd, partial, (int)N, (int)C, (int)HW, P)
 #define OFASR_BNA(VEC, ACT, RES)                                                                                     \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC, ACT, RES>), grid, dim3(BN_THREADS), 0, st, (const T*)dy,         \
-                       (const T*)x, (const T*)residual, (T*)dx, (T*)dresidual, scale, shift, mean, invstd, coef,     \
-                       (int)N, (int)C, (int)HW, P)
+                       (const T*)x, (const T*)residual, (T*)dx, (T*)dresidual, scale, shift, mean, invstd,           \
+                       (const double*)partial, P, M, training, dgamma, dbeta, (int)N, (int)C, (int)HW, P)
 #define OFASR_BN_BOTH(MACRO)                                                                              \
     OFASR_BN_DISPATCH_T(dtype, {                                                                          \
         if (v) {                                                                                          \
@@ -494,10 +578,6 @@ OFASR_EXPORT int ofasr_bn_act_bwd(const void* dy, const void* x, const void* res
     OFASR_BN_BOTH(OFASR_BNR);
     rc = check_launch(name);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, partial, P, (int)C,
-                       (double)N * (double)HW, scale, mean, invstd, training, dgamma, dbeta, coef);
-    rc = check_launch(name);
-    if (rc) return rc;
     OFASR_BN_BOTH(OFASR_BNA);
 #undef OFASR_BNR
 #undef OFASR_BNA
@@ -507,5 +587,5 @@ OFASR_EXPORT int ofasr_bn_act_bwd(const void* dy, const void* x, const void* res
 
 OFASR_EXPORT size_t ofasr_bn_act_bwd_workspace(int64_t N, int64_t C) {
     if (N <= 0 || C <= 0) return 0;
-    return (size_t)bn_parts(N, C) * C * 2 * sizeof(double) + (size_t)C * 3 * sizeof(float);
+    return (size_t)bn_parts(N, C) * C * 2 * sizeof(double);
 }

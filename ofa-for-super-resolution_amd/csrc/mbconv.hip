@@ -93,18 +93,9 @@ static int bn_forward(const ofasr_mbconv_desc* d, int which, const void* x, cons
                       int act, float* stat_buf, void* ws, size_t ws_bytes, void* stream) {
     const int64_t HW = d->H * d->W;
     StatView sv = stat_view(stat_buf, which, d->mid, d->Cout);
-    int rc;
-    int64_t np = 0;
-    if (d->bn_training[which]) {
-        rc = ofasr_bn_stats(x, d->N, C, HW, d->dtype, ws, ws_bytes, stream);
-        if (rc) return rc;
-        np = ofasr_bn_partials(d->N, C);
-    }
-    rc = ofasr_bn_finalize(ws, np, C, (double)(d->N * HW), d->gamma[which], d->beta[which], d->running_mean[which],
-                           d->running_var[which], d->bn_momentum[which], d->bn_eps[which], d->bn_training[which],
-                           sv.mean, sv.invstd, sv.scale, sv.shift, stream);
-    if (rc) return rc;
-    return ofasr_bn_act_fwd(x, res, y, sv.scale, sv.shift, sv.mean, d->N, C, HW, act, d->dtype, stream);
+    return ofasr_bn_fwd(x, res, y, d->gamma[which], d->beta[which], d->running_mean[which], d->running_var[which],
+                        d->bn_momentum[which], d->bn_eps[which], d->bn_training[which], sv.mean, d->N, C, HW, act,
+                        d->dtype, ws, ws_bytes, stream);
 }
 
 }  // namespace ofasr

@@ -326,30 +326,20 @@ class BNActFn(Function):
         w = _f32_param(weight)
         b = _f32_param(bias)
         stats = torch.empty((4, C), dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
-        mean, invstd, scale, shift = stats[0], stats[1], stats[2], stats[3]
-        wst = None
-        if training:
-            wst, wsp, wsn = _ws(L.ofasr_bn_workspace(N, C), dev)
-            with _timed("bn_stats", x.numel() * x.element_size()):
-                _C.check(L.ofasr_bn_stats(_p(x), N, C, HW, _dt(x), wsp, wsn, _stream()), "bn_stats")
-            nparts = L.ofasr_bn_partials(N, C)
-        else:
-            wsp, nparts = ctypes.c_void_p(None), 0
-        rm = _p(running_mean) if running_mean is not None else ctypes.c_void_p(None)
-        rv = _p(running_var) if running_var is not None else ctypes.c_void_p(None)
-        _C.check(L.ofasr_bn_finalize(wsp, nparts, C, float(N * HW), _p(w), _p(b), rm, rv, float(momentum), float(eps),
-                                     1 if training else 0, _p(mean), _p(invstd), _p(scale), _p(shift), _stream()),
-                 "bn_finalize")
         if residual is not None:
             residual = residual.contiguous()
             if residual.shape != x.shape or residual.dtype != x.dtype:
                 raise _C.OfasrError("bn_act: residual %s/%s does not match x %s/%s" % (
                     tuple(residual.shape), residual.dtype, tuple(x.shape), x.dtype))
         y = torch.empty_like(x)
+        wst, wsp, wsn = _ws(L.ofasr_bn_workspace(N, C) if training else 0, dev)
+        rm = _p(running_mean) if running_mean is not None else ctypes.c_void_p(None)
+        rv = _p(running_var) if running_var is not None else ctypes.c_void_p(None)
         rp = _p(residual) if residual is not None else ctypes.c_void_p(None)
-        with _timed("bn_act_fwd", (2 + (residual is not None)) * x.numel() * x.element_size()):
-            _C.check(L.ofasr_bn_act_fwd(_p(x), rp, _p(y), _p(scale), _p(shift), _p(mean), N, C, HW, act, _dt(x),
-                                        _stream()), "bn_act_fwd")
+        with _timed("bn_fwd", (3 + (residual is not None)) * x.numel() * x.element_size()):
+            _C.check(L.ofasr_bn_fwd(_p(x), rp, _p(y), _p(w), _p(b), rm, rv, float(momentum), float(eps),
+                                    1 if training else 0, _p(stats), N, C, HW, act, _dt(x), wsp, wsn, _stream()),
+                     "bn_fwd")
         keep_res = residual if (residual is not None and act != ACT_NONE) else None
         ctx.save_for_backward(x, stats, keep_res)
         ctx.meta = (bool(training), act, residual is not None, tuple(weight.shape))
