@@ -60,6 +60,11 @@ SIGNATURES = {
     "ofasr_bn_act_bwd_workspace": (_c_sz, [_c_i64, _c_i64]),
     "ofasr_bn_act_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                   _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
+    "ofasr_conv2d_workspace": (_c_sz, [_c_i64, _c_i64, _c_int, _c_int]),
+    "ofasr_conv2d_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp,
+                                  _c_sz, _c_vp]),
+    "ofasr_conv2d_dgrad": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp,
+                                    _c_sz, _c_vp]),
     "ofasr_mbconv_workspace": (_c_sz, [_c_vp]),
     "ofasr_mbconv_stat_floats": (_c_sz, [_c_vp]),
     "ofasr_mbconv_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),

@@ -105,7 +105,7 @@ class ConvLayer(My2DLayer):
         if not (ops.FUSED_BN and self.ops_order == "weight_bn_act" and self.use_bn and self.dropout_rate == 0
                 and x.is_cuda):
             return super().forward(x)
-        x = self.conv(x)
+        x = ops.conv2d(x, self.conv)
         if self.act_func == "relu6":
             return ops.bn_act(x, self.bn, ops.ACT_RELU6)
         x = ops.bn_act(x, self.bn, ops.ACT_NONE)

@@ -472,3 +472,68 @@ class FusedMBConvFn(Function):
             _C.check(L.ofasr_mbconv_bwd(ctypes.byref(d), _p(x), _p(act), _p(stat), _p(dout), _p(dx), _p(tmp),
                                         ctypes.byref(g), _p(ws), ws.numel(), _stream()), "mbconv_bwd")
         return (dx, None, dw1, dg1, db1, dwdw, dg2, db2, dw2, dg3, db3) + tuple(dmats)
+
+
+# ------------------------------------------------------------------------------- dense KxK conv
+HIP_CONV = True   # static ConvLayer convolutions (16-bit activations) through the implicit-GEMM HIP kernel
+
+
+def _conv_hip_ok(x, weight, stride, padding, dilation, groups):
+    k = weight.shape[-1]
+    return (HIP_CONV and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and weight.dtype == torch.float32
+            and weight.shape[2] == weight.shape[3] and k in (3, 5) and stride == (1, 1) and dilation == (1, 1)
+            and groups == 1 and padding == (k // 2, k // 2) and x.shape[3] % 8 == 0)
+
+
+class Conv2dFn(Function):
+    """nn.Conv2d of the static ConvLayer (reference ofa/layers.py:131-151) for 16-bit activations: forward and input
+    gradient on the implicit-GEMM MFMA kernel (csrc/conv2d.hip); the weight gradient is the vendor library's
+    (aten.convolution_backward, weight-only mask) until the HIP wgrad lands."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        N, Cin, H, W = x.shape
+        Cout, _, K, _ = weight.shape
+        L = _C.lib()
+        y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=x.device)
+        wst, wsp, wsn = _ws(L.ofasr_conv2d_workspace(Cin, Cout, K, 0), x.device)
+        with _timed("conv2d_fwd_%dto%d_k%d" % (Cin, Cout, K), (x.numel() + y.numel()) * x.element_size(),
+                    2 * N * H * W * Cin * Cout * K * K):
+            _C.check(L.ofasr_conv2d_fwd(_p(x), _p(weight), _p(y), N, Cin, Cout, H, W, K, _dt(x), wsp, wsn, _stream()),
+                     "conv2d_fwd")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        N, Cin, H, W = x.shape
+        Cout, _, K, _ = weight.shape
+        dy = dy.contiguous()
+        L = _C.lib()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            wst, wsp, wsn = _ws(L.ofasr_conv2d_workspace(Cin, Cout, K, 1), x.device)
+            with _timed("conv2d_dgrad_%dto%d_k%d" % (Cout, Cin, K), (x.numel() + dy.numel()) * x.element_size(),
+                        2 * N * H * W * Cin * Cout * K * K):
+                _C.check(L.ofasr_conv2d_dgrad(_p(dy), _p(weight), _p(dx), N, Cin, Cout, H, W, K, _dt(x), wsp, wsn,
+                                              _stream()), "conv2d_dgrad")
+        if ctx.needs_input_grad[1]:
+            w16 = weight.to(x.dtype)
+            dw = torch.ops.aten.convolution_backward(dy, x, w16, None, [1, 1], [K // 2, K // 2], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1].float()
+        return dx, dw
+
+
+def conv2d(x, conv):
+    """forward of the nn.Conv2d module `conv`: HIP implicit GEMM when the shape/dtype qualifies, else the module."""
+    if conv.bias is None and torch.is_autocast_enabled() and x.is_cuda and x.dtype == torch.float32:
+        xa = x.to(torch.get_autocast_dtype("cuda"))
+    else:
+        xa = x
+    if conv.bias is None and _conv_hip_ok(xa, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
+        return Conv2dFn.apply(xa, conv.weight)
+    return conv(x)

@@ -77,6 +77,34 @@ def main():
     y256 = torch.empty(N, 64, 2 * S, 2 * S, device=dev, dtype=dt)
     cases.append(("pixel_shuffle 256ch", 2 * x256.numel() * es,
                   lambda: L.ofasr_pixel_shuffle(P(x256), P(y256), N, 64, S, S, 2, es, st)))
+    import torch.nn.functional as F
+    flops = {}
+    for (ci, co, hh, K) in ((3, 64, S, 5), (64, 256, S, 5), (64, 256, 2 * S, 5), (64, 3, 4 * S, 5), (64, 64, S, 3)):
+        if a.dtype == "f32":
+            break
+        xc = torch.randn(N, ci, hh, hh, device=dev).to(dt)
+        yc = torch.randn(N, co, hh, hh, device=dev).to(dt)
+        wc = torch.randn(co, ci, K, K, device=dev) * 0.05
+        w16 = wc.to(dt)
+        nb = (xc.numel() + yc.numel()) * es
+        fl = 2.0 * N * hh * hh * ci * co * K * K
+        for nm, fn in (("conv2d_fwd %d->%d k%d @%d" % (ci, co, K, hh),
+                        lambda xc=xc, yc=yc, wc=wc, ci=ci, co=co, hh=hh, K=K: L.ofasr_conv2d_fwd(
+                            P(xc), P(wc), P(yc), N, ci, co, hh, hh, K, code, P(ws), wsn, st)),
+                       ("conv2d_dgrad %d<-%d k%d @%d" % (ci, co, K, hh),
+                        lambda xc=xc, yc=yc, wc=wc, ci=ci, co=co, hh=hh, K=K: L.ofasr_conv2d_dgrad(
+                            P(yc), P(wc), P(xc), N, ci, co, hh, hh, K, code, P(ws), wsn, st)),
+                       ("miopen  fwd %d->%d k%d @%d" % (ci, co, K, hh),
+                        lambda xc=xc, w16=w16, K=K: (F.conv2d(xc, w16, padding=K // 2), 0)[1]),
+                       ("miopen  bwd(dx,dw) %d->%d k%d @%d" % (ci, co, K, hh),
+                        lambda xc=xc, yc=yc, w16=w16, K=K: (torch.ops.aten.convolution_backward(
+                            yc, xc, w16, None, [1, 1], [K // 2, K // 2], [1, 1], False, [0, 0], 1, [True, True, False]), 0)[1]),
+                       ("miopen  bwd(dw) %d->%d k%d @%d" % (ci, co, K, hh),
+                        lambda xc=xc, yc=yc, w16=w16, K=K: (torch.ops.aten.convolution_backward(
+                            yc, xc, w16, None, [1, 1], [K // 2, K // 2], [1, 1], False, [0, 0], 1, [False, True, False]), 0)[1])):
+            cases.append((nm, nb, fn))
+            flops[nm] = fl
+    torch.backends.cudnn.benchmark = True
     for name, nbytes, fn in cases:
         if a.only and a.only not in name:
             continue
@@ -91,7 +119,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / a.reps
-        print("%-36s %8.1f us  %8.1f GB/s  (%.1f MB algorithmic)" % (name, us, nbytes / us / 1e3, nbytes / 1e6))
+        extra = "  %7.1f TFLOP/s" % (flops[name] / us / 1e6) if name in flops else ""
+        print("%-36s %8.1f us  %8.1f GB/s  (%.1f MB algorithmic)%s" % (name, us, nbytes / us / 1e3, nbytes / 1e6, extra))
 
 
 if __name__ == "__main__":
