@@ -189,14 +189,30 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     const float* f = stat_buf + 8 * d->mid + 4 * d->Cout;
     const int kmax = d->ks[0];
 
-    // dense parameter gradients: zero everything, the kernels fill the active slices
-    hipError_t e = hipMemsetAsync(g->dw1, 0, (size_t)d->Cmid_max * d->ldw1 * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(g->dw2, 0, (size_t)d->Cout_max * d->ldw2 * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(g->dwdw_max, 0, (size_t)d->Cmid_max * kmax * kmax * sizeof(float), st);
-    for (int i = 0; i < 3 && e == hipSuccess; ++i) {
-        const size_t n = (size_t)(i < 2 ? d->Cmid_max : d->Cout_max) * sizeof(float);
-        e = hipMemsetAsync(g->dgamma[i], 0, n, st);
-        if (e == hipSuccess) e = hipMemsetAsync(g->dbeta[i], 0, n, st);
+    // dense parameter gradients: zero everything, the kernels fill the active slices.  The host mirror hands out
+    // the nine buffers as slices of one allocation: then a single fill covers them (one launch instead of ~18).
+    struct Span { char* p; size_t n; };
+    const Span sp[9] = {{(char*)g->dw1, (size_t)d->Cmid_max * d->ldw1 * sizeof(float)},
+                        {(char*)g->dw2, (size_t)d->Cout_max * d->ldw2 * sizeof(float)},
+                        {(char*)g->dwdw_max, (size_t)d->Cmid_max * kmax * kmax * sizeof(float)},
+                        {(char*)g->dgamma[0], (size_t)d->Cmid_max * sizeof(float)},
+                        {(char*)g->dbeta[0], (size_t)d->Cmid_max * sizeof(float)},
+                        {(char*)g->dgamma[1], (size_t)d->Cmid_max * sizeof(float)},
+                        {(char*)g->dbeta[1], (size_t)d->Cmid_max * sizeof(float)},
+                        {(char*)g->dgamma[2], (size_t)d->Cout_max * sizeof(float)},
+                        {(char*)g->dbeta[2], (size_t)d->Cout_max * sizeof(float)}};
+    char *lo = sp[0].p, *hi = sp[0].p + sp[0].n;
+    size_t sum = 0;
+    for (const Span& q : sp) {
+        lo = q.p < lo ? q.p : lo;
+        hi = q.p + q.n > hi ? q.p + q.n : hi;
+        sum += q.n;
+    }
+    hipError_t e = hipSuccess;
+    if ((size_t)(hi - lo) == sum) {   // disjoint spans (validated above) tiling [lo, hi) exactly
+        e = hipMemsetAsync(lo, 0, sum, st);
+    } else {
+        for (int i = 0; i < 9 && e == hipSuccess; ++i) e = hipMemsetAsync(sp[i].p, 0, sp[i].n, st);
     }
     OFASR_REQUIRE(e == hipSuccess, OFASR_ERR_LAUNCH, "%s: memset failed: %s", name, hipGetErrorString(e));
 

@@ -454,14 +454,14 @@ class FusedMBConvFn(Function):
         dout = dout.contiguous()
         dx = torch.empty_like(x)
         tmp = torch.empty(N * HW * (2 * d.mid + d.Cout), dtype=x.dtype, device=x.device)
-        sizes = [w1.numel(), w2.numel(), wdw.numel()] + [m.numel() for m in mats] + [g1.numel()] * 2 + [g2.numel()] * 2 \
-            + [g3.numel()] * 2
+        # the nine zero-initialised buffers first and adjacent: the library then clears them with one fill
+        sizes = [w1.numel(), w2.numel(), wdw.numel()] + [g1.numel()] * 2 + [g2.numel()] * 2 + [g3.numel()] * 2 \
+            + [m.numel() for m in mats]
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=x.device)
         parts = flat.split(sizes)
         dw1, dw2, dwdw = parts[0].view_as(w1), parts[1].view_as(w2), parts[2].view_as(wdw)
-        nm = len(mats)
-        dmats = [parts[3 + i].view_as(mats[i]) for i in range(nm)]
-        dg1, db1, dg2, db2, dg3, db3 = parts[3 + nm:]
+        dg1, db1, dg2, db2, dg3, db3 = parts[3:9]
+        dmats = [parts[9 + i].view_as(mats[i]) for i in range(len(mats))]
         g = _C.MBConvGrads()
         g.dw1, g.dw2, g.dwdw_max = dw1.data_ptr(), dw2.data_ptr(), dwdw.data_ptr()
         for i, m in enumerate(dmats):
@@ -475,6 +475,7 @@ class FusedMBConvFn(Function):
 
 
 # ------------------------------------------------------------------------------- dense KxK conv
+CONV_FORCE_HIP = False   # tests: every qualifying conv through the HIP kernel regardless of the measured policy
 HIP_CONV = True   # static ConvLayer convolutions (16-bit activations) through the implicit-GEMM HIP kernel
 
 
@@ -491,10 +492,11 @@ class Conv2dFn(Function):
     (aten.convolution_backward, weight-only mask) until the HIP wgrad lands."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, dgrad_hip=True):
         x = x.contiguous()
         N, Cin, H, W = x.shape
         Cout, _, K, _ = weight.shape
+        ctx.dgrad_hip = dgrad_hip
         L = _C.lib()
         y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=x.device)
         wst, wsp, wsn = _ws(L.ofasr_conv2d_workspace(Cin, Cout, K, 0), x.device)
@@ -514,6 +516,12 @@ class Conv2dFn(Function):
         dy = dy.contiguous()
         L = _C.lib()
         dx = dw = None
+        if not ctx.dgrad_hip:
+            w16 = weight.to(x.dtype)
+            dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w16, None, [1, 1], [K // 2, K // 2], [1, 1], False,
+                                                            [0, 0], 1, [ctx.needs_input_grad[0],
+                                                                        ctx.needs_input_grad[1], False])
+            return dx, (dw.float() if dw is not None else None), None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wst, wsp, wsn = _ws(L.ofasr_conv2d_workspace(Cin, Cout, K, 1), x.device)
@@ -525,7 +533,13 @@ class Conv2dFn(Function):
             w16 = weight.to(x.dtype)
             dw = torch.ops.aten.convolution_backward(dy, x, w16, None, [1, 1], [K // 2, K // 2], [1, 1], False, [0, 0], 1,
                                                      [False, True, False])[1].float()
-        return dx, dw
+        return dx, dw, None
+
+
+def _conv_policy(cin, cout, k):
+    """(forward on HIP, backward-data on HIP) -- measured on MI355X (tools/kbench.py, profiles/r01_kbench.txt): the HIP
+    kernel wins for thin outputs (the 64->3 head) and 3x3; the vendor kernels win the wide 5x5 up-sampler convs."""
+    return (cout <= 32 or k == 3), (k == 3)
 
 
 def conv2d(x, conv):
@@ -535,5 +549,8 @@ def conv2d(x, conv):
     else:
         xa = x
     if conv.bias is None and _conv_hip_ok(xa, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
-        return Conv2dFn.apply(xa, conv.weight)
+        w = conv.weight
+        fwd_hip, bwd_hip = _conv_policy(w.shape[1], w.shape[0], w.shape[2])
+        if fwd_hip or CONV_FORCE_HIP:
+            return Conv2dFn.apply(xa, w, bwd_hip or CONV_FORCE_HIP)
     return conv(x)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Aggregate a rocprofv3 kernel-trace CSV over the last N training steps (steps are delimited by the
-optimizer's multi_tensor_apply launches).  usage: tools_trace_steps.py <kernel_trace.csv> [nsteps] [top]"""
+optimizer's multi_tensor_apply launches), optionally skipping the last `skip` steps (bench.py ends with 7 instrumented
+per-op steps for the roofline figure).  usage: trace_steps.py <kernel_trace.csv> [nsteps] [top] [skip]"""
 import collections
 import csv
 import sys
@@ -10,12 +11,13 @@ def main():
     path = sys.argv[1]
     nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+    skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     rows = list(csv.DictReader(open(path)))
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
     names = [e[2] for e in ev]
     opt = [i for i, n in enumerate(names) if "multi_tensor_apply" in n]
     ends = [i for j, i in enumerate(opt) if j == len(opt) - 1 or opt[j + 1] - i > 50]
-    lo, hi = ends[-(nsteps + 1)] + 1, ends[-1] + 1
+    lo, hi = ends[-(nsteps + 1 + skip)] + 1, ends[-1 - skip] + 1
     sel = ev[lo:hi]
     span = (sel[-1][1] - sel[0][0]) / 1e6
     agg = collections.defaultdict(lambda: [0, 0])
