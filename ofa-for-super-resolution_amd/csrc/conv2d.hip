@@ -3,23 +3,25 @@
 //
 // Replaces nn.Conv2d in ConvLayer (reference ofa/layers.py:131-151; stem, residual convs, the two
 // conv -> BN -> PixelShuffle up-sampling blocks and the output conv of OFAMobileNetS4, ofa_mbs4.py:65,105,120,123).
-// These five layers are 68 % of the step's FLOPs at 4x; MIOpen runs them as NHWC iGEMM
-// kernels wrapped in NCHW<->NHWC transposes at ~9 % of the bf16 MFMA peak.
+// These five layers are 68 % of the step's FLOPs at 4x.
 //
 //   Y[n, m, h, w] = sum_{tap=(ty,tx)} sum_{k} Wimg[tap][m][k] * X[n, k, h+ty-pad, w+tx-pad]
 //
 // forward: (m, k) = (co, ci); input gradient: the same kernel on dY with (m, k) = (ci, co) and the 180-degree
 // rotated taps.  Roofline: MFMA (K = 25*Cin = 1600 for the 5x5 64-channel layers => AI >> ridge).
 //
-// Block = 2 output rows x 64 columns of one image x one slab of output channels.
-//   * the (2+K-1) x (64+K-1) input window of a 64-channel chunk is staged ONCE into LDS, transposed to
-//     [pixel][channel] so a B fragment (8 channels of one pixel) is one ds_read_b128; pixels of a row are stored
-//     in 4 column-phase segments (col & 3), so the lanes of a fragment read -- which own columns 4c+t+tx -- touch
-//     consecutive 128-byte records and the XOR swizzle of the 16-byte chunks makes the read conflict-free;
-//   * weights come from a pre-swizzled bf16 image [tap][slab][chunk] (built per call by conv_prep_kernel from
-//     the fp32 master weights, 0.8 MB for 5x5x64x256, L2-resident) and are copied tile by tile into LDS;
-//   * MFMA column c of sub-tile t is the pixel (row c>>4, column 4*(c&15)+t): a lane owns 4 adjacent output
-//     pixels and stores them with one 8-byte access.
+// Block = (2*WP) output rows x 64 columns of one image x (64*WM or 32*WM) output channels; a wave owns RB 32-row
+// blocks x 2 rows x 64 columns (4 MFMA sub-tiles: column c of sub-tile t is the pixel (row c>>4, column 4*(c&15)+t),
+// so a lane owns 4 adjacent output pixels and stores them with one 8-byte access).
+//   * B operand: the (TH+K-1) x (64+K-1) input window of a 32-channel chunk is staged ONCE into LDS transposed to
+//     [pixel][32 channels] 64-byte records (8x8 register transposes, 16-byte LDS stores), so a B fragment (8
+//     channels of one pixel) is one ds_read_b128.  Pixels of a window row sit in 4 column-phase segments (col & 3):
+//     the lanes of a fragment read -- which own columns 4c+t+tx -- then touch consecutive records, and the XOR of
+//     the 16-byte chunk index with (record>>2)&3 makes every 16-lane group of the read conflict-free.
+//     For one (ty, k-step) the K*4 (tx, t) MFMAs of a row block need only the 8 fragments u = t+tx in [0, 8).
+//   * A operand: straight from a fragment-ordered bf16 weight image (built per call by conv_prep_kernel from the
+//     fp32 master weights; 0.8 MB for 5x5x64x256, L2-resident): one coalesced 16-byte load per lane per fragment,
+//     re-issued one (ty, k-step) ahead into the registers the MFMAs just released.  No LDS, no barrier per tap.
 #include "ofasr_common.h"
 
 namespace ofasr {
@@ -29,11 +31,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 cv_bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 cv_f16x8;
 typedef __attribute__((ext_vector_type(8))) short cv_s16x8;
 
-constexpr int CV_THREADS = 256;
 constexpr int CV_TW = 64;     // output tile width
-constexpr int CV_TH = 2;      // output tile height
-constexpr int CV_SEG = 20;    // positions per column-phase segment (>= ceil(68 / 4); 4*SEG % 16 == 0 keeps the two
-constexpr int CV_RP = 4 * CV_SEG;   // tile rows of a ds_read_b128 lane group on disjoint bank slots)
+constexpr int CV_SEG = 20;    // records per column-phase segment (>= ceil((64 + 4) / 4))
+constexpr int CV_RP = 4 * CV_SEG;   // records per window row; % 16 == 0 keeps both rows of a lane group bank-disjoint
+constexpr int CV_KC = 32;     // channels per staged chunk (64-byte records)
 
 template <typename T> struct CvMma;
 template <> struct CvMma<bf16_t> {
@@ -49,171 +50,179 @@ template <> struct CvMma<f16_t> {
     }
 };
 
-// [rows][64 k] 16-bit operand tile: 128-byte rows, 16-byte chunks XOR-swizzled (same format as pwconv.hip)
-__device__ __host__ __forceinline__ int cv_tile_off(int row, int k) {
-    return row * 128 + ((((k >> 3) ^ ((row >> 1) & 7)) << 4)) + (k & 7) * 2;
-}
-__device__ __forceinline__ int cv_tile_chunk(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-// LDS record index of input-window pixel (r, col): rows of 68 records, 4 column-phase segments per row
+// LDS record index of window pixel (r, col), and the byte offset of its 8-channel group j (0..3)
 __device__ __forceinline__ int cv_pos(int r, int col) { return r * CV_RP + (col & 3) * CV_SEG + (col >> 2); }
+__device__ __forceinline__ int cv_rec(int P, int j) { return P * 64 + ((j ^ ((P >> 2) & 3)) << 4); }
 
-// wave decomposition: MODE 0: 128-row slab, wave = row block, 4 sub-tiles;  1: 64 rows, wave = (row block, pixel half);
-// 2: 32 rows, wave = pixel quarter
-template <int MODE> struct CvMode;
-template <> struct CvMode<0> { static constexpr int ROWS = 128, NSUB = 4; };
-template <> struct CvMode<1> { static constexpr int ROWS = 64, NSUB = 2; };
-template <> struct CvMode<2> { static constexpr int ROWS = 32, NSUB = 1; };
-
-// ---- weight image: [tap][slab][kchunk] tiles of [ROWS][64] in the swizzled operand format
+// ---- weight image: 16-byte A fragments in consumption order [kc][ty][s][tx][row block][lane]
+//      lane (r = lane&31, h = lane>>5) holds rows 32*rb + r, k = 32*kc + 16*s + 8*h + (0..7)
 template <typename T>
-__global__ void __launch_bounds__(256) conv_prep_kernel(const float* __restrict__ w, T* __restrict__ wimg, int Cout,
-                                                        int Cin, int KS, int dgrad, int M, int Kdim, int rows, int nslab,
-                                                        int nkc, long long total) {
+__global__ void __launch_bounds__(256) conv_prep_kernel(const float* __restrict__ w, T* __restrict__ wimg, int Cin,
+                                                        int KS, int dgrad, int M, int Kdim, int nrb, long long total) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int k = (int)(idx & 63);
-    long long t = idx >> 6;
-    const int r = (int)(t % rows);
-    t /= rows;
-    const int kc = (int)(t % nkc);
-    t /= nkc;
-    const int slab = (int)(t % nslab);
-    const int tap = (int)(t / nslab);
-    const int m = slab * rows + r, kk = kc * 64 + k;
+    const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    long long t = idx >> 9;
+    const int rb = (int)(t % nrb);
+    t /= nrb;
+    const int tx = (int)(t % KS);
+    t /= KS;
+    const int s = (int)(t & 1);
+    t >>= 1;
+    const int ty = (int)(t % KS);
+    const int kc = (int)(t / KS);
+    const int m = rb * 32 + (lane & 31), kk = kc * CV_KC + 16 * s + 8 * (lane >> 5) + j;
     float v = 0.f;
     if (m < M && kk < Kdim) {
-        const int taps = KS * KS;
+        const int taps = KS * KS, tap = ty * KS + tx;
         v = dgrad ? w[((long long)kk * Cin + m) * taps + (taps - 1 - tap)]    // rows = ci, k = co, rotated tap
                   : w[((long long)m * Cin + kk) * taps + tap];                // rows = co, k = ci
     }
-    const long long tile = ((long long)tap * nslab + slab) * nkc + kc;
-    char* base = reinterpret_cast<char*>(wimg) + tile * (long long)rows * 128;
-    *reinterpret_cast<uint16_t*>(base + cv_tile_off(r, k)) = from_float<T>(v).v;
+    wimg[idx] = from_float<T>(v);
 }
 
-template <typename T, int KS, int MODE>
-__global__ void __launch_bounds__(CV_THREADS) conv_igemm_kernel(const T* __restrict__ x, const T* __restrict__ wimg,
-                                                                T* __restrict__ y, int Cx, int M, int H, int W,
-                                                                int tiles_x, int nkc) {
+template <typename T, int KS, int RB, int WM, int WP, bool ONEK>
+__global__ void __launch_bounds__(64 * WM * WP, 2) conv_igemm_kernel(const T* __restrict__ x, const T* __restrict__ wimg,
+                                                                     T* __restrict__ y, int Cx, int M, int H, int W,
+                                                                     int tiles_x, int nkc, int nrb) {
+    constexpr int THREADS = 64 * WM * WP;
     constexpr int PAD = KS / 2;
-    constexpr int RH = CV_TH + KS - 1;
+    constexpr int TH = 2 * WP;
+    constexpr int RH = TH + KS - 1;
     constexpr int RW = CV_TW + KS - 1;
-    constexpr int ROWS = CvMode<MODE>::ROWS;
-    constexpr int NSUB = CvMode<MODE>::NSUB;
-    __shared__ __attribute__((aligned(16))) char Xt[RH * CV_RP * 128];
-    __shared__ __attribute__((aligned(16))) char Wt[ROWS * 128];
+    constexpr int NIT = 2 * KS;   // (ty, k-step) iterations per chunk
+    __shared__ __attribute__((aligned(16))) char Xt[RH * CV_RP * 64];
 
     const int tile = blockIdx.x;
-    const int ty0 = (tile / tiles_x) * CV_TH, tx0 = (tile % tiles_x) * CV_TW;
-    const int n = blockIdx.y, slab = blockIdx.z, nslab = gridDim.z;
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * CV_TW;
+    const int n = blockIdx.y, slab = blockIdx.z;
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wm = wave % WM, wp = wave / WM;
     const int c = lane & 31, h = lane >> 5;
-    const int cb = MODE == 0 ? wave : (MODE == 1 ? (wave & 1) : 0);
-    const int sub0 = MODE == 0 ? 0 : (MODE == 1 ? 2 * (wave >> 1) : wave);
-    const int prow = c >> 4, pcol = 4 * (c & 15);   // this lane's pixel inside the tile (column of sub-tile 0)
+    const int prow = 2 * wp + (c >> 4), pcol = 4 * (c & 15);   // this lane's pixel inside the tile (sub-tile 0)
+    const int grb0 = (slab * WM + wm) * RB;                    // first global row block of this wave
 
-    cv_f32x16 acc[NSUB];
+    // B-fragment addresses: record P = P0 + D(ty, u) with the lane part P0 = prow*RP + (c&15) and the compile-time
+    // D = ty*RP + (u&3)*SEG + (u>>2).  The swizzle key ((P>>2)&3) = (K0 + (D>>2) + carry)&3 with K0 = (P0>>2)&3 and
+    // carry = ((c&3) == 3 && u >= 4): 2 (carry sets) x 4 (key deltas) x 2 (k-steps) base registers, the rest is the
+    // instruction's immediate offset.
+    const int P0 = prow * CV_RP + (c & 15);
+    int bbase[2][4][2];
 #pragma unroll
-    for (int t = 0; t < NSUB; ++t)
+    for (int cs = 0; cs < 2; ++cs)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int key = (((P0 >> 2) & 3) + m + (cs && (c & 3) == 3 ? 1 : 0)) & 3;
+                bbase[cs][m][ks] = P0 * 64 + (((2 * ks + h) ^ key) << 4);
+            }
+    auto read_b = [&](int ty, int u, int ks) -> cv_s16x8 {
+        const int D = ty * CV_RP + (u & 3) * CV_SEG + (u >> 2);
+        return *reinterpret_cast<const cv_s16x8*>(Xt + bbase[u >> 2][(D >> 2) & 3][ks] + D * 64);
+    };
+
+    cv_f32x16 acc[RB][4];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][t][i] = 0.f;
 
     const T* xn = x + (long long)n * Cx * H * W;
+    const uint4* wbase = reinterpret_cast<const uint4*>(wimg);   // wave-uniform: fragment addresses stay in SGPRs
     for (int kc = 0; kc < nkc; ++kc) {
-        __syncthreads();   // previous chunk's readers are done with Xt / Wt
-        // ---- stage the input window of channels [64kc, 64kc+64): aligned 16-byte runs of 8 columns, transposed
-        //      into [pixel][channel] records
-        constexpr int NCH = (CV_TW + 16) / 8;   // 10 runs cover columns [tx0-8, tx0+72)
-        constexpr int TOTAL = 64 * RH * NCH;
-        constexpr int BATCH = 5;   // independent 16-byte loads in flight per thread, then their LDS scatter
-#pragma unroll 1
-        for (int q0 = 0; q0 < TOTAL; q0 += BATCH * CV_THREADS) {
-            uint4 v[BATCH];
+        // A fragments of iteration 0 (their latency hides behind the staging below)
+        cv_s16x8 A[KS][RB];
+        const long long it_stride = (long long)KS * nrb * 64;   // uint4 per (ty, s) iteration
+        const uint4* wk = wbase + (long long)kc * NIT * it_stride + (long long)grb0 * 64;
 #pragma unroll
-            for (int it = 0; it < BATCH; ++it) {
-                const int q = q0 + tid + it * CV_THREADS;
-                const int ch = q % NCH;
-                const int r = (q / NCH) % RH;
-                const int ci = q / (NCH * RH);
-                const int gy = ty0 - PAD + r;
-                const int gx = tx0 - 8 + 8 * ch;
-                v[it] = make_uint4(0, 0, 0, 0);
-                if (q < TOTAL && 64 * kc + ci < Cx && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                    v[it] = *reinterpret_cast<const uint4*>(xn + ((long long)(64 * kc + ci) * H + gy) * W + gx);
+        for (int tx = 0; tx < KS; ++tx)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                A[tx][rb] = __builtin_bit_cast(cv_s16x8, (wk + ((long long)tx * nrb + rb) * 64)[lane]);
+
+        __syncthreads();   // previous chunk's readers are done with Xt
+        // ---- stage the window of channels [32kc, 32kc+32): task = (8-channel group, window row, 8-column run);
+        //      8 x 16-byte loads, 8x8 16-bit transpose in registers, 8 x 16-byte record stores
+        constexpr int NRUN = (CV_TW + 16) / 8;   // 10 runs cover columns [tx0-8, tx0+72)
+        constexpr int NTASK = 4 * RH * NRUN;
+#pragma unroll 1
+        for (int q = tid; q < NTASK; q += THREADS) {
+            const int run = q % NRUN;
+            const int r = (q / NRUN) % RH;
+            const int g = q / (NRUN * RH);
+            const int gy = ty0 - PAD + r;
+            const int gx = tx0 - 8 + 8 * run;
+            const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int cbase = CV_KC * kc + 8 * g;
+            uint4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = make_uint4(0, 0, 0, 0);
+                if (inb && cbase + i < Cx)
+                    v[i] = *reinterpret_cast<const uint4*>(xn + ((long long)(cbase + i) * H + gy) * W + gx);
             }
 #pragma unroll
-            for (int it = 0; it < BATCH; ++it) {
-                const int q = q0 + tid + it * CV_THREADS;
-                if (q < TOTAL) {
-                    const int ch = q % NCH;
-                    const int r = (q / NCH) % RH;
-                    const int ci = q / (NCH * RH);
-                    const uint32_t wds[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
-                    const int cisw = ci >> 3, cioff = (ci & 7) * 2;
+            for (int k = 0; k < 4; ++k) {   // dword k of every channel: pixels 2k, 2k+1
+                uint32_t lo[4], hi[4];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int tcol = 8 * ch - 8 + PAD + i;   // column inside the staged window
-                        if (tcol >= 0 && tcol < RW) {
-                            const int P = cv_pos(r, tcol);
-                            const uint16_t e = (uint16_t)(i & 1 ? (wds[i >> 1] >> 16) : (wds[i >> 1] & 0xffffu));
-                            *reinterpret_cast<uint16_t*>(Xt + P * 128 + (((cisw ^ ((P >> 1) & 7)) << 4)) + cioff) = e;
-                        }
-                    }
+                for (int m = 0; m < 4; ++m) {
+                    const uint32_t a = k == 0 ? v[2 * m].x : k == 1 ? v[2 * m].y : k == 2 ? v[2 * m].z : v[2 * m].w;
+                    const uint32_t b = k == 0 ? v[2 * m + 1].x : k == 1 ? v[2 * m + 1].y : k == 2 ? v[2 * m + 1].z
+                                                                                                  : v[2 * m + 1].w;
+                    lo[m] = __builtin_amdgcn_perm(b, a, 0x05040100u);
+                    hi[m] = __builtin_amdgcn_perm(b, a, 0x07060302u);
                 }
+                const int tc0 = 8 * run - 8 + PAD + 2 * k;   // window column of pixel 2k
+                if (tc0 >= 0 && tc0 < RW)
+                    *reinterpret_cast<uint4*>(Xt + cv_rec(cv_pos(r, tc0), g)) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                if (tc0 + 1 >= 0 && tc0 + 1 < RW)
+                    *reinterpret_cast<uint4*>(Xt + cv_rec(cv_pos(r, tc0 + 1), g)) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
             }
         }
-        const int nks = min(4, (Cx - 64 * kc + 15) >> 4);   // 16-channel k-steps that hold data
-        // weight tiles: the next tap's tile is fetched into registers while the current tap computes
-        constexpr int WIT = ROWS * 8 / CV_THREADS;   // uint4 per thread per tile (4 / 2 / 1)
-        const char* wbase = reinterpret_cast<const char*>(wimg) + ((long long)slab * nkc + kc) * (ROWS * 128);
-        const long long wtap = (long long)nslab * nkc * (ROWS * 128);
-        uint4 wreg[WIT];
+        __syncthreads();
+
+        // (ty, k-step) iterations; ONEK (K <= 16: the 3-channel stem / head gradient) walks k-step 0 only
+        constexpr int STEP = ONEK ? 2 : 1;
 #pragma unroll
-        for (int j = 0; j < WIT; ++j) wreg[j] = reinterpret_cast<const uint4*>(wbase)[tid + j * CV_THREADS];
-        for (int tap = 0; tap < KS * KS; ++tap) {
-            __syncthreads();   // Xt staged (first tap) / previous tap's Wt readers done
+        for (int it = 0; it < NIT; it += STEP) {
+            const int ty = it >> 1, ks = it & 1;
+            cv_s16x8 B[8];
 #pragma unroll
-            for (int j = 0; j < WIT; ++j) reinterpret_cast<uint4*>(Wt)[tid + j * CV_THREADS] = wreg[j];
-            __syncthreads();
-            if (tap + 1 < KS * KS) {
+            for (int u = 0; u < KS + 3; ++u) B[u] = read_b(ty, u, ks);
 #pragma unroll
-                for (int j = 0; j < WIT; ++j)
-                    wreg[j] = reinterpret_cast<const uint4*>(wbase + (tap + 1) * wtap)[tid + j * CV_THREADS];
-            }
-            const int ty = tap / KS, tx = tap - ty * KS;
+            for (int tx = 0; tx < KS; ++tx) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (s < nks) {
-                    const cv_s16x8 af = *reinterpret_cast<const cv_s16x8*>(Wt + cv_tile_chunk(32 * cb + c, 2 * s + h));
+                for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                    for (int t = 0; t < NSUB; ++t) {
-                        const int P = cv_pos(prow + ty, pcol + sub0 + t + tx);
-                        const cv_s16x8 bf =
-                            *reinterpret_cast<const cv_s16x8*>(Xt + P * 128 + (((2 * s + h) ^ ((P >> 1) & 7)) << 4));
-                        acc[t] = CvMma<T>::run(af, bf, acc[t]);
-                    }
+                    for (int t = 0; t < 4; ++t) acc[rb][t] = CvMma<T>::run(A[tx][rb], B[t + tx], acc[rb][t]);
+                __builtin_amdgcn_sched_barrier(0);   // keep the refill below the MFMAs that free its registers
+                if (it + STEP < NIT) {
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+                        A[tx][rb] = __builtin_bit_cast(
+                            cv_s16x8, (wk + (it + STEP) * it_stride + ((long long)tx * nrb + rb) * 64)[lane]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
-    // ---- epilogue: lane owns NSUB adjacent pixels of row (ty0 + prow) for 16 output channels
-    const int oy = ty0 + prow, ox = tx0 + pcol + sub0;
+    // ---- epilogue: lane owns 4 adjacent pixels of row (ty0 + prow) for 16 output channels per row block
+    const int oy = ty0 + prow, ox = tx0 + pcol;
     if (oy < H && ox < W) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int m = slab * ROWS + 32 * cb + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            if (m < M) {
-                T* dst = y + (((long long)n * M + m) * H + oy) * W + ox;
-                if constexpr (NSUB == 4) {
-                    *reinterpret_cast<uint2*>(dst) =
-                        make_uint2(pack2<T>(acc[0][reg], acc[1][reg]), pack2<T>(acc[2][reg], acc[3][reg]));
-                } else if constexpr (NSUB == 2) {
-                    *reinterpret_cast<uint32_t*>(dst) = pack2<T>(acc[0][reg], acc[1][reg]);
-                } else {
-                    *dst = from_float<T>(acc[0][reg]);
+        for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = (grb0 + rb) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (m < M) {
+                    T* dst = y + (((long long)n * M + m) * H + oy) * W + ox;
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(pack2<T>(acc[rb][0][reg], acc[rb][1][reg]),
+                                                                pack2<T>(acc[rb][2][reg], acc[rb][3][reg]));
                 }
             }
         }
@@ -222,42 +231,59 @@ __global__ void __launch_bounds__(CV_THREADS) conv_igemm_kernel(const T* __restr
 
 struct CvPlan {
     bool ok;
-    int mode, rows, nslab, nkc, M, Kdim;
+    int cfg;        // 0: 256 rows/block (RB2 WM4 WP1); 1: 128 (RB2 WM2 WP2); 2: 64 (RB2 WM1 WP4); 3: 32 (RB1 WM1 WP4);
+                    // 4: 64 rows as RB1 WM2 WP2 (4-row tiles: twice the blocks of cfg 2 for small images)
+    int rows, th, threads, nslab, nrb, nkc, M, Kdim;
     size_t img_bytes;
 };
 
-static CvPlan cv_plan(int64_t Cin, int64_t Cout, int K, int dgrad) {
+static CvPlan cv_plan(int64_t Cin, int64_t Cout, int K, int dgrad, int64_t N = 0, int64_t H = 0, int64_t W = 0) {
     CvPlan p{};
     p.M = (int)(dgrad ? Cin : Cout);
     p.Kdim = (int)(dgrad ? Cout : Cin);
     p.ok = (K == 3 || K == 5) && p.M > 0 && p.Kdim > 0;
-    p.mode = p.M > 64 ? 0 : (p.M > 32 ? 1 : 2);
-    p.rows = p.mode == 0 ? 128 : (p.mode == 1 ? 64 : 32);
+    p.cfg = p.M > 128 ? 0 : (p.M > 64 ? 1 : (p.M > 32 ? 2 : 3));
+    // the weight image does not depend on the (N, H, W)-driven choice between cfg 2 and 4 (same 64-row slabs)
+    if (p.cfg == 2 && N > 0 && N * cdiv(H, 8) * cdiv(W, CV_TW) < 512) p.cfg = 4;
+    p.rows = p.cfg == 0 ? 256 : (p.cfg == 1 ? 128 : (p.cfg == 3 ? 32 : 64));
+    p.th = p.cfg == 0 ? 2 : ((p.cfg == 1 || p.cfg == 4) ? 4 : 8);
+    p.threads = 256;
     p.nslab = (int)cdiv(p.M, p.rows);
-    p.nkc = (int)cdiv(p.Kdim, 64);
-    p.img_bytes = (size_t)K * K * p.nslab * p.nkc * p.rows * 128;
+    p.nrb = p.nslab * (p.rows / 32);
+    p.nkc = (int)cdiv(p.Kdim, CV_KC);
+    p.img_bytes = (size_t)p.nkc * K * 2 * K * p.nrb * 1024;
     return p;
 }
 
 template <typename T>
 static int launch_conv2d(const char* name, const void* x, const float* w, void* y, int64_t N, int64_t Cin, int64_t Cout,
                          int64_t H, int64_t W, int K, int dgrad, void* ws, hipStream_t st) {
-    const CvPlan p = cv_plan(Cin, Cout, K, dgrad);
-    const long long total = (long long)K * K * p.nslab * p.nkc * p.rows * 64;
-    hipLaunchKernelGGL((conv_prep_kernel<T>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, w, (T*)ws, (int)Cout,
-                       (int)Cin, K, dgrad, p.M, p.Kdim, p.rows, p.nslab, p.nkc, total);
+    const CvPlan p = cv_plan(Cin, Cout, K, dgrad, N, H, W);
+    const long long total = (long long)(p.img_bytes / 2);
+    hipLaunchKernelGGL((conv_prep_kernel<T>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, w, (T*)ws, (int)Cin, K,
+                       dgrad, p.M, p.Kdim, p.nrb, total);
     int rc = check_launch(name);
     if (rc) return rc;
-    const int tiles_x = (int)cdiv(W, CV_TW), tiles_y = (int)cdiv(H, CV_TH);
+    const int tiles_x = (int)cdiv(W, CV_TW), tiles_y = (int)cdiv(H, p.th);
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)N, (unsigned)p.nslab);
-#define OFASR_CV(KS, MODE)                                                                                         \
-    hipLaunchKernelGGL((conv_igemm_kernel<T, KS, MODE>), grid, dim3(CV_THREADS), 0, st, (const T*)x, (const T*)ws,  \
-                       (T*)y, p.Kdim, p.M, (int)H, (int)W, tiles_x, p.nkc)
-    if (K == 5) {
-        if (p.mode == 0) OFASR_CV(5, 0); else if (p.mode == 1) OFASR_CV(5, 1); else OFASR_CV(5, 2);
-    } else {
-        if (p.mode == 0) OFASR_CV(3, 0); else if (p.mode == 1) OFASR_CV(3, 1); else OFASR_CV(3, 2);
+#define OFASR_CV(KS, RB, WM, WP, ONEK)                                                                                  \
+    hipLaunchKernelGGL((conv_igemm_kernel<T, KS, RB, WM, WP, ONEK>), grid, dim3(64 * WM * WP), 0, st, (const T*)x,         \
+                       (const T*)ws, (T*)y, p.Kdim, p.M, (int)H, (int)W, tiles_x, p.nkc, p.nrb)
+#define OFASR_CVK(KS, ONEK)                                                                                         \
+    switch (p.cfg) {                                                                                                \
+        case 0: OFASR_CV(KS, 2, 4, 1, ONEK); break;                                                                 \
+        case 1: OFASR_CV(KS, 2, 2, 2, ONEK); break;                                                                 \
+        case 2: OFASR_CV(KS, 2, 1, 4, ONEK); break;                                                                 \
+        case 4: OFASR_CV(KS, 1, 2, 2, ONEK); break;                                                                 \
+        default: OFASR_CV(KS, 1, 1, 4, ONEK); break;                                                                \
     }
+    const bool onek = p.Kdim <= 16;
+    if (K == 5) {
+        if (onek) { OFASR_CVK(5, true) } else { OFASR_CVK(5, false) }
+    } else {
+        if (onek) { OFASR_CVK(3, true) } else { OFASR_CVK(3, false) }
+    }
+#undef OFASR_CVK
 #undef OFASR_CV
     return check_launch(name);
 }

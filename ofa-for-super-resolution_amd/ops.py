@@ -537,9 +537,9 @@ class Conv2dFn(Function):
 
 
 def _conv_policy(cin, cout, k):
-    """(forward on HIP, backward-data on HIP) -- measured on MI355X (tools/kbench.py, profiles/r01_kbench.txt): the HIP
-    kernel wins for thin outputs (the 64->3 head) and 3x3; the vendor kernels win the wide 5x5 up-sampler convs."""
-    return (cout <= 32 or k == 3), (k == 3)
+    """(forward on HIP, backward-data on HIP) -- measured on MI355X (tools/kbench.py, profiles/r01_kbench.txt): the
+    implicit-GEMM kernel beats the vendor kernels (which also pay NCHW<->NHWC transposes) on every static conv."""
+    return True, True
 
 
 def conv2d(x, conv):
