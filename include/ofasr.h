@@ -212,15 +212,20 @@ int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, const void* act_
 /* ---------------------------------------------------------------------------------------------
  * Dense KxK convolution (K in {3,5}, stride 1, zero padding K/2, no bias) of the static ConvLayers as an
  * implicit GEMM on the matrix cores  -- replaces nn.Conv2d in ConvLayer (reference ofa/layers.py:131-151) for
- * 16-bit activations: forward and input gradient (the weight gradient stays on the vendor library for now).
- *   x [N,Cin,H,W], y [N,Cout,H,W] (f16 / bf16), w [Cout,Cin,K,K] fp32; needs W % 8 == 0.
- * workspace: the per-call bf16 weight image, ofasr_conv2d_workspace(Cin, Cout, K, dgrad) bytes.
+ * 16-bit activations: forward, input gradient and weight gradient.
+ *   x [N,Cin,H,W], y [N,Cout,H,W] (f16 / bf16), w / dw [Cout,Cin,K,K] fp32; needs W % 8 == 0.
+ * workspace: fwd / dgrad: the per-call 16-bit weight image, ofasr_conv2d_workspace(Cin, Cout, K, dgrad) bytes;
+ *            wgrad: the split-K partial slabs, ofasr_conv2d_wgrad_workspace(N, Cin, Cout, H, W, K) bytes.
+ * ofasr_conv2d_wgrad writes every element of dw (no accumulation into it); the summation order is fixed.
  * Returns OFASR_ERR_UNSUPPORTED for fp32 / other K / unaligned shapes (the caller then uses the vendor path).
  * ------------------------------------------------------------------------------------------- */
 size_t ofasr_conv2d_workspace(int64_t Cin, int64_t Cout, int K, int dgrad);
 int ofasr_conv2d_fwd(const void* x, const float* w, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
                      int K, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 int ofasr_conv2d_dgrad(const void* dy, const float* w, void* dx, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
+                       int64_t W, int K, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+size_t ofasr_conv2d_wgrad_workspace(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K);
+int ofasr_conv2d_wgrad(const void* dy, const void* x, float* dw, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
                        int64_t W, int K, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus

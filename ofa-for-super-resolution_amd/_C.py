@@ -65,6 +65,9 @@ SIGNATURES = {
                                   _c_sz, _c_vp]),
     "ofasr_conv2d_dgrad": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp,
                                     _c_sz, _c_vp]),
+    "ofasr_conv2d_wgrad_workspace": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int]),
+    "ofasr_conv2d_wgrad": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp,
+                                    _c_sz, _c_vp]),
     "ofasr_mbconv_workspace": (_c_sz, [_c_vp]),
     "ofasr_mbconv_stat_floats": (_c_sz, [_c_vp]),
     "ofasr_mbconv_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),

@@ -288,6 +288,292 @@ static int launch_conv2d(const char* name, const void* x, const float* w, void* 
     return check_launch(name);
 }
 
+// ================================================================================= weight gradient
+//   dW[co, ci, ty, tx] = sum_{n, h, w} dY[n, co, h, w] * X[n, ci, h + ty - pad, w + tx - pad]
+// GEMM with k = pixels.  A block owns (a slab of output channels) x (64 or 32 input channels) x ONE kernel row ty and
+// a contiguous range of 2x64-pixel tiles (split-K); it keeps the K accumulators (tx = 0..K-1) of its row blocks in
+// registers across the whole range and writes them once, in accumulator order, to its slab; conv_wgrad_reduce_kernel
+// sums the slabs in a fixed order (deterministic) and scatters into the [Cout, Cin, K, K] fp32 gradient.
+//   * A (dY, rows = co): the tile is copied as is ([co][128 pixels], 16-byte chunks XOR-swizzled with row&15) --
+//     8 consecutive pixels of one channel are contiguous in NCHW, one ds_read_b128 per fragment;
+//   * B (X, cols = ci): the 2 x 80 pixel window of kernel row ty is transposed on the way in to [pixel][ci] records
+//     (8x8 register transposes, as the forward kernel) and read with ds_read_b64_tr_b16, so the tap shift tx is a
+//     whole-record offset and needs no alignment.
+// wave = (row-block group wco, 32-channel column block wci, k-step phase wk).
+typedef __attribute__((ext_vector_type(4))) short cv_s16x4;
+typedef __attribute__((address_space(3))) cv_s16x4 cv_lds_s16x4;
+
+struct CvWgParams {
+    int Cin, Cout, H, W, tiles_x, tiles_y, ntiles, ksplit, ncislab, nz;
+};
+
+template <int WCI> __device__ __forceinline__ int cvw_xoff(int R, int chunk) {   // byte offset of 16-byte chunk in record R
+    if constexpr (WCI == 2) return R * 128 + ((((chunk >> 2) ^ ((R >> 1) & 1))) << 6) + ((chunk & 3) << 4);
+    else return R * 64 + (chunk << 4);
+}
+
+template <typename T, int KS, int RBW, int WCO, int WCI, int WK>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            float* __restrict__ part, CvWgParams P) {
+    static_assert(WCO * WCI * WK == 4, "4 waves");
+    constexpr int PAD = KS / 2;
+    constexpr int CIB = 32 * WCI;            // input channels per block
+    constexpr int REC = 2 * CIB;             // bytes per pixel record
+    constexpr int ROWS = 32 * RBW * WCO;     // output channels per block
+    constexpr int XW = 80;                   // staged window columns [tx0-8, tx0+72)
+    __shared__ __attribute__((aligned(16))) char Yt[ROWS * 256];
+    __shared__ __attribute__((aligned(16))) char Xt[2 * XW * REC];
+
+    const int split = blockIdx.x, ty = blockIdx.y, z = blockIdx.z;
+    const int coslab = z / P.ncislab, cislab = z % P.ncislab;
+    const int tid = threadIdx.x, lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wco = wave % WCO, wci = (wave / WCO) % WCI, wk = wave / (WCO * WCI);
+    const int c = lane & 31, h = lane >> 5;
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+
+    // B read bases: byte offset of this lane's 4 channels in record L, with the 64-byte-half swizzle of the
+    // 128-byte records resolved for the four (bit 1, bit 0) classes of the compile-time record delta D
+    int xbase[2][2];
+    {
+        const int L = 8 * (g >> 1) + q;
+        const int cb = 64 * wci + 32 * (g & 1) + 8 * pp;
+#pragma unroll
+        for (int b1 = 0; b1 < 2; ++b1)
+#pragma unroll
+            for (int b0 = 0; b0 < 2; ++b0) {
+                if constexpr (WCI == 2) {
+                    const int bit1 = ((L >> 1) & 1) ^ b1 ^ (b0 & L & 1);   // bit 1 of (L + D)
+                    xbase[b1][b0] = L * 128 + ((wci ^ bit1) << 6) + (cb & 63);
+                } else {
+                    xbase[b1][b0] = L * 64 + cb;
+                }
+            }
+    }
+    cv_f32x16 acc[RBW][KS];
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int tx = 0; tx < KS; ++tx)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][tx][i] = 0.f;
+
+    const long long HW = (long long)P.H * P.W;
+    const int t0 = (int)((long long)split * P.ntiles / P.ksplit), t1 = (int)((long long)(split + 1) * P.ntiles / P.ksplit);
+    const int tpi = P.tiles_x * P.tiles_y;
+    for (int tile = t0; tile < t1; ++tile) {
+        const int n = tile / tpi, trem = tile - n * tpi;
+        const int ty0 = (trem / P.tiles_x) * 2, tx0 = (trem % P.tiles_x) * CV_TW;
+        const T* xn = x + (long long)n * P.Cin * HW;
+        const T* dyn = dy + (long long)n * P.Cout * HW;
+        __syncthreads();   // previous tile's readers are done
+        // ---- X window of kernel row ty: task = (8-channel group, row, 8-column run)
+        constexpr int NXT = (CIB / 8) * 2 * 10;
+        if (tid < NXT) {
+            const int run = tid % 10, r = (tid / 10) & 1, cg = tid / 20;
+            const int gy = ty0 + r + ty - PAD, gx = tx0 - 8 + 8 * run;
+            const bool inb = gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+            const int cbase = cislab * CIB + 8 * cg;
+            uint4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = make_uint4(0, 0, 0, 0);
+                if (inb && cbase + i < P.Cin) v[i] = *reinterpret_cast<const uint4*>(xn + ((long long)(cbase + i) * P.H + gy) * P.W + gx);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t lo[4], hi[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const uint32_t a = k == 0 ? v[2 * m].x : k == 1 ? v[2 * m].y : k == 2 ? v[2 * m].z : v[2 * m].w;
+                    const uint32_t b = k == 0 ? v[2 * m + 1].x : k == 1 ? v[2 * m + 1].y : k == 2 ? v[2 * m + 1].z
+                                                                                                  : v[2 * m + 1].w;
+                    lo[m] = __builtin_amdgcn_perm(b, a, 0x05040100u);
+                    hi[m] = __builtin_amdgcn_perm(b, a, 0x07060302u);
+                }
+                const int R = r * XW + 8 * run + 2 * k;
+                *reinterpret_cast<uint4*>(Xt + cvw_xoff<WCI>(R, cg)) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                *reinterpret_cast<uint4*>(Xt + cvw_xoff<WCI>(R + 1, cg)) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            }
+        }
+        // ---- dY tile: [co][2 rows x 64 px], 16-byte chunks
+        constexpr int NYT = ROWS * 16;
+#pragma unroll
+        for (int i0 = 0; i0 < NYT; i0 += 4 * 256) {
+            uint4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = i0 + j * 256 + tid;
+                const int chunk = idx & 15, row = idx >> 4;
+                const int co = coslab * ROWS + row, gy = ty0 + (chunk >> 3), gx = tx0 + 8 * (chunk & 7);
+                v[j] = make_uint4(0, 0, 0, 0);
+                if (idx < NYT && co < P.Cout && gy < P.H && gx < P.W)
+                    v[j] = *reinterpret_cast<const uint4*>(dyn + ((long long)co * P.H + gy) * P.W + gx);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = i0 + j * 256 + tid;
+                const int chunk = idx & 15, row = idx >> 4;
+                if (idx < NYT) *reinterpret_cast<uint4*>(Yt + row * 256 + ((chunk ^ (row & 15)) << 4)) = v[j];
+            }
+        }
+        __syncthreads();
+        // ---- 8 k-steps of 16 pixels; this wave takes every WK-th
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if ((s % WK) != wk) continue;
+            cv_s16x8 A[RBW];
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) {
+                const int row = 32 * (wco * RBW + rb) + c;
+                A[rb] = *reinterpret_cast<const cv_s16x8*>(Yt + row * 256 + (((2 * s + h) ^ (row & 15)) << 4));
+            }
+            // k row of this lane's transposing read: pixel 16s + 8*(g>>1) + q (+4); window record = L + D with the
+            // lane part L = 8*(g>>1) + q and the compile-time D = row*XW + 16*(s&3) + 8 - PAD + tx (+4)
+#pragma unroll
+            for (int tx = 0; tx < KS; ++tx) {
+                const int Da = (s >> 2) * XW + 16 * (s & 3) + 8 - PAD + tx, Db = Da + 4;
+                const cv_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (cv_lds_s16x4*)(Xt + xbase[(Da >> 1) & 1][Da & 1] + Da * REC));
+                const cv_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (cv_lds_s16x4*)(Xt + xbase[(Db >> 1) & 1][Db & 1] + Db * REC));
+                const cv_s16x8 B = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int rb = 0; rb < RBW; ++rb) acc[rb][tx] = CvMma<T>::run(A[rb], B, acc[rb][tx]);
+            }
+        }
+    }
+    // ---- k-step phases of one (wco, wci) add up inside the block, one tx slice (RBW*4 KB per wave) at a time
+    const int wq = wave % (WCO * WCI);
+    if constexpr (WK > 1) {
+        static_assert(WCO * WCI * RBW * 4096 <= ROWS * 256, "Yt holds one tx slice per (wco, wci)");
+        float* red = reinterpret_cast<float*>(Yt) + wq * (RBW * 16 * 64) + lane;
+#pragma unroll
+        for (int tx = 0; tx < KS; ++tx) {
+#pragma unroll
+            for (int ph = 1; ph < WK; ++ph) {
+                __syncthreads();
+                if (wk == ph) {
+#pragma unroll
+                    for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) red[(rb * 16 + reg) * 64] = acc[rb][tx][reg];
+                }
+                __syncthreads();
+                if (wk == 0) {
+#pragma unroll
+                    for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) acc[rb][tx][reg] += red[(rb * 16 + reg) * 64];
+                }
+            }
+        }
+        if (wk != 0) return;
+    }
+    // ---- slab: [split][ty][z][wq][rb][tx][reg][lane]
+    float* dst = part + ((((long long)split * KS + ty) * P.nz + z) * (WCO * WCI) + wq) * (RBW * KS * 16 * 64) + lane;
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int tx = 0; tx < KS; ++tx)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) dst[((rb * KS + tx) * 16 + reg) * 64] = acc[rb][tx][reg];
+}
+
+// one thread per (ty, z, wco, wci, rb, tx, reg, lane): sums over the splits in order, scatters into dW
+template <int KS, int RBW, int WCO, int WCI>
+__global__ void __launch_bounds__(256) conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                CvWgParams P, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    constexpr int PER_WAVE = RBW * KS * 16 * 64;
+    long long t = idx;
+    const int lane = (int)(t & 63);
+    t >>= 6;
+    const int reg = (int)(t & 15);
+    t >>= 4;
+    const int tx = (int)(t % KS);
+    t /= KS;
+    const int rb = (int)(t % RBW);
+    t /= RBW;
+    const int wq = (int)(t % (WCO * WCI));   // wave index without the k-phase
+    t /= (WCO * WCI);
+    const int z = (int)(t % P.nz);
+    const int ty = (int)(t / P.nz);
+    const int wco = wq % WCO, wci = wq / WCO;
+    const int coslab = z / P.ncislab, cislab = z % P.ncislab;
+    const int co = coslab * (32 * RBW * WCO) + 32 * (wco * RBW + rb) + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    const int ci = cislab * (32 * WCI) + 32 * wci + (lane & 31);
+    if (co >= P.Cout || ci >= P.Cin) return;
+    const long long inner = ((long long)(rb * KS + tx) * 16 + reg) * 64 + lane;
+    float sum = 0.f;
+    const long long sstride = (long long)KS * P.nz * (WCO * WCI) * PER_WAVE;
+    const float* src = part + (((long long)ty * P.nz + z) * (WCO * WCI) + wq) * PER_WAVE + inner;
+    for (int split = 0; split < P.ksplit; ++split) sum += src[split * sstride];
+    dw[(((long long)co * P.Cin + ci) * KS + ty) * KS + tx] = sum;
+}
+
+struct CvWgPlan {
+    int cfg;   // WCI = 2 (64-channel slabs): 0: RBW2 WCO2 WK1, 1: RBW2 WCO1 WK2, 2: RBW1 WCO1 WK2;
+               // WCI = 1 (<= 32 input channels per slab): 3: RBW2 WCO2 WK2 (as two k phases), 4: RBW2 WCO1 WK4, 5: RBW1 WCO1 WK4
+    int rows, cib, rbw;
+    CvWgParams P;
+    size_t part_bytes;
+};
+
+static CvWgPlan cv_wg_plan(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K) {
+    CvWgPlan p{};
+    const bool wide = Cin > 32;
+    const int rcls = Cout > 64 ? 0 : (Cout > 32 ? 1 : 2);
+    p.cfg = (wide ? 0 : 3) + rcls;
+    p.rows = rcls == 0 ? 128 : (rcls == 1 ? 64 : 32);
+    p.rbw = rcls == 2 ? 1 : 2;
+    p.cib = wide ? 64 : 32;
+    CvWgParams& P = p.P;
+    P.Cin = (int)Cin; P.Cout = (int)Cout; P.H = (int)H; P.W = (int)W;
+    P.tiles_x = (int)cdiv(W, CV_TW); P.tiles_y = (int)cdiv(H, 2);
+    P.ntiles = (int)(N * P.tiles_x * P.tiles_y);
+    P.ncislab = (int)cdiv(Cin, p.cib);
+    P.nz = (int)cdiv(Cout, p.rows) * P.ncislab;
+    // two blocks per CU, but at least 8 pixel tiles per block (every split costs a 40 KB slab per wave)
+    int ks = 512 / (K * P.nz);
+    ks = ks > P.ntiles / 8 ? P.ntiles / 8 : ks;
+    P.ksplit = ks < 1 ? 1 : ks;
+    const int nwq = wide ? (rcls == 0 ? 4 : 2) : (rcls == 0 ? 2 : 1);   // (wco, wci) pairs per block
+    p.part_bytes = (size_t)P.ksplit * K * P.nz * nwq * (p.rbw * K * 16 * 64) * sizeof(float);
+    return p;
+}
+
+template <typename T>
+static int launch_conv2d_wgrad(const char* name, const void* dy, const void* x, float* dw, int K, const CvWgPlan& p, void* ws,
+                               hipStream_t st) {
+    const CvWgParams& P = p.P;
+    dim3 grid((unsigned)P.ksplit, (unsigned)K, (unsigned)P.nz);
+#define OFASR_WG(KS, RBW, WCO, WCI, WK)                                                                              \
+    {                                                                                                                \
+        hipLaunchKernelGGL((conv_wgrad_kernel<T, KS, RBW, WCO, WCI, WK>), grid, dim3(256), 0, st, (const T*)dy,      \
+                           (const T*)x, (float*)ws, P);                                                              \
+        int rc = check_launch(name);                                                                                 \
+        if (rc) return rc;                                                                                           \
+        const long long tot = (long long)KS * P.nz * (WCO * WCI) * RBW * KS * 16 * 64;                               \
+        hipLaunchKernelGGL((conv_wgrad_reduce_kernel<KS, RBW, WCO, WCI>), dim3((unsigned)cdiv(tot, 256)),            \
+                           dim3(256), 0, st, (const float*)ws, dw, P, tot);                                          \
+    }
+#define OFASR_WGK(KS)                                                                                                \
+    switch (p.cfg) {                                                                                                 \
+        case 0: OFASR_WG(KS, 2, 2, 2, 1) break;                                                                      \
+        case 1: OFASR_WG(KS, 2, 1, 2, 2) break;                                                                      \
+        case 2: OFASR_WG(KS, 1, 1, 2, 2) break;                                                                      \
+        case 3: OFASR_WG(KS, 2, 2, 1, 2) break;                                                                      \
+        case 4: OFASR_WG(KS, 2, 1, 1, 4) break;                                                                      \
+        default: OFASR_WG(KS, 1, 1, 1, 4) break;                                                                     \
+    }
+    if (K == 5) { OFASR_WGK(5) } else { OFASR_WGK(3) }
+#undef OFASR_WGK
+#undef OFASR_WG
+    return check_launch(name);
+}
+
 static int conv2d_entry(const char* name, const void* x, const float* w, void* y, int64_t N, int64_t Cin, int64_t Cout,
                         int64_t H, int64_t W, int K, int dtype, int dgrad, void* ws, size_t ws_bytes, void* stream) {
     OFASR_REQUIRE(x && w && y, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
@@ -325,4 +611,29 @@ OFASR_EXPORT int ofasr_conv2d_dgrad(const void* dy, const float* w, void* dx, in
                                     void* stream) {
     return conv2d_entry("ofasr_conv2d_dgrad", dy, w, dx, N, Cin, Cout, H, W, K, dtype, 1, workspace, workspace_bytes,
                         stream);
+}
+
+OFASR_EXPORT size_t ofasr_conv2d_wgrad_workspace(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || !(K == 3 || K == 5)) return 0;
+    return cv_wg_plan(N, Cin, Cout, H, W, K).part_bytes;
+}
+
+OFASR_EXPORT int ofasr_conv2d_wgrad(const void* dy, const void* x, float* dw, int64_t N, int64_t Cin, int64_t Cout,
+                                    int64_t H, int64_t W, int K, int dtype, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    const char* name = "ofasr_conv2d_wgrad";
+    OFASR_REQUIRE(dy && x && dw, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, OFASR_ERR_INVALID_ARG, "%s: bad shape", name);
+    OFASR_REQUIRE(dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_UNSUPPORTED,
+                  "%s: 16-bit activations only (fp32 runs on the vendor library)", name);
+    OFASR_REQUIRE(K == 3 || K == 5, OFASR_ERR_UNSUPPORTED, "%s: K=%d not in {3,5}", name, K);
+    OFASR_REQUIRE(W % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0,
+                  OFASR_ERR_UNSUPPORTED, "%s: needs W %% 8 == 0 and 16-byte aligned tensors", name);
+    OFASR_REQUIRE(N * H * W <= (1LL << 30), OFASR_ERR_UNSUPPORTED, "%s: too large", name);
+    const CvWgPlan p = cv_wg_plan(N, Cin, Cout, H, W, K);
+    OFASR_REQUIRE(workspace && workspace_bytes >= p.part_bytes, OFASR_ERR_WORKSPACE,
+                  "%s: workspace %zu B < required %zu B", name, workspace_bytes, p.part_bytes);
+    hipStream_t st = as_stream(stream);
+    if (dtype == OFASR_BF16) return launch_conv2d_wgrad<bf16_t>(name, dy, x, dw, K, p, workspace, st);
+    return launch_conv2d_wgrad<f16_t>(name, dy, x, dw, K, p, workspace, st);
 }

@@ -487,9 +487,8 @@ def _conv_hip_ok(x, weight, stride, padding, dilation, groups):
 
 
 class Conv2dFn(Function):
-    """nn.Conv2d of the static ConvLayer (reference ofa/layers.py:131-151) for 16-bit activations: forward and input
-    gradient on the implicit-GEMM MFMA kernel (csrc/conv2d.hip); the weight gradient is the vendor library's
-    (aten.convolution_backward, weight-only mask) until the HIP wgrad lands."""
+    """nn.Conv2d of the static ConvLayer (reference ofa/layers.py:131-151) for 16-bit activations: forward, input
+    and weight gradients on the implicit-GEMM MFMA kernels (csrc/conv2d.hip)."""
 
     @staticmethod
     def forward(ctx, x, weight, dgrad_hip=True):
@@ -530,9 +529,12 @@ class Conv2dFn(Function):
                 _C.check(L.ofasr_conv2d_dgrad(_p(dy), _p(weight), _p(dx), N, Cin, Cout, H, W, K, _dt(x), wsp, wsn,
                                               _stream()), "conv2d_dgrad")
         if ctx.needs_input_grad[1]:
-            w16 = weight.to(x.dtype)
-            dw = torch.ops.aten.convolution_backward(dy, x, w16, None, [1, 1], [K // 2, K // 2], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1].float()
+            dw = torch.empty_like(weight)
+            wst, wsp, wsn = _ws(L.ofasr_conv2d_wgrad_workspace(N, Cin, Cout, H, W, K), x.device)
+            with _timed("conv2d_wgrad_%dto%d_k%d" % (Cin, Cout, K), (x.numel() + dy.numel()) * x.element_size(),
+                        2 * N * H * W * Cin * Cout * K * K):
+                _C.check(L.ofasr_conv2d_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Cout, H, W, K, _dt(x), wsp, wsn, _stream()),
+                         "conv2d_wgrad")
         return dx, dw, None
 
 

@@ -43,7 +43,7 @@ def main():
     dw2 = torch.zeros_like(w2)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
-    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
     wsn = ctypes.c_size_t(ws.numel())
     cases = []
     act_big = (N * (64 + mid) * HW) * es
@@ -94,6 +94,9 @@ def main():
                        ("conv2d_dgrad %d<-%d k%d @%d" % (ci, co, K, hh),
                         lambda xc=xc, yc=yc, wc=wc, ci=ci, co=co, hh=hh, K=K: L.ofasr_conv2d_dgrad(
                             P(yc), P(wc), P(xc), N, ci, co, hh, hh, K, code, P(ws), wsn, st)),
+                       ("conv2d_wgrad %d->%d k%d @%d" % (ci, co, K, hh),
+                        lambda xc=xc, yc=yc, wc=wc, ci=ci, co=co, hh=hh, K=K: L.ofasr_conv2d_wgrad(
+                            P(yc), P(xc), P(wc), N, ci, co, hh, hh, K, code, P(ws), wsn, st)),
                        ("miopen  fwd %d->%d k%d @%d" % (ci, co, K, hh),
                         lambda xc=xc, w16=w16, K=K: (F.conv2d(xc, w16, padding=K // 2), 0)[1]),
                        ("miopen  bwd(dx,dw) %d->%d k%d @%d" % (ci, co, K, hh),
