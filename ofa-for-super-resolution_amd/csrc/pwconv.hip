@@ -562,6 +562,92 @@ __global__ void __launch_bounds__(256) pw_wgrad_reduce_kernel(const float* __res
     }
 }
 
+// ---- 16-bit aligned fast path: no LDS, no barrier (measured 24.6 us + 7.2 us reduce vs 33.1 + 5.0 for the staged
+// kernel on 16x384x64x64; per-lane 16-byte loads of 32 different lines run at ~1 lane/clk in the address path, so
+// the kernel wants as many blocks as CUs).  With k = pixels BOTH operands of out(r, s) = sum_px R[r][px]*S[s][px]
+// have their 8 k-values contiguous in NCHW, so a fragment is a plain 16-byte global load.  The k-slot <-> pixel map is
+// free as long as A and B agree: lane (row, h) owns the 32 pixels [64q + 32h, +32) of quad q -- 64 contiguous bytes,
+// consumed by the quad's 4 k-steps -- so the two lanes of a row cover one full 128-byte line.
+// block = 8 waves = 4 row groups (3 row blocks each: 384 rows) x 2 column blocks (64 cols); grid.x = split-K.
+constexpr int WD_RB = 3;
+constexpr int WD_ROWS = 4 * WD_RB * 32, WD_COLS = 64;
+
+struct WdPlan {
+    int quads_per_img, total_quads, nsplit, MR, NS;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restrict__ R, const T* __restrict__ S,
+                                                              float* __restrict__ part, int MR, int NS, int HW,
+                                                              WdPlan wp) {
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wr = wave & 3, wc = wave >> 2;
+    const int c = lane & 31, h = lane >> 5;
+    const int split = blockIdx.x;
+    const int row0 = blockIdx.y * WD_ROWS + wr * (WD_RB * 32);   // first row of this wave
+    const int col = blockIdx.z * WD_COLS + wc * 32 + c;          // this lane's S channel
+    if (row0 >= MR) return;   // no rows (and no slab rows) for this wave; the kernel has no barrier
+    f32x16 acc[WD_RB];
+#pragma unroll
+    for (int rb = 0; rb < WD_RB; ++rb) acc[rb] = zero16();
+    const int q0 = (int)((long long)split * wp.total_quads / wp.nsplit);
+    const int q1 = (int)((long long)(split + 1) * wp.total_quads / wp.nsplit);
+    const bool cs = col < NS;
+    bool rs[WD_RB];
+#pragma unroll
+    for (int rb = 0; rb < WD_RB; ++rb) rs[rb] = row0 + 32 * rb + c < MR;
+    for (int q = q0; q < q1; ++q) {
+        const int n = q / wp.quads_per_img;
+        const int px = (q - n * wp.quads_per_img) * 64 + 32 * h;   // this lane's first pixel
+        uint4 a[WD_RB][4], b[4];
+        const T* sp = S + ((long long)n * NS + col) * HW + px;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b[j] = make_uint4(0, 0, 0, 0);
+            if (cs && px + 8 * j < HW) b[j] = *reinterpret_cast<const uint4*>(sp + 8 * j);
+        }
+#pragma unroll
+        for (int rb = 0; rb < WD_RB; ++rb) {
+            const T* rp = R + ((long long)n * MR + row0 + 32 * rb + c) * HW + px;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[rb][j] = make_uint4(0, 0, 0, 0);
+                if (rs[rb] && px + 8 * j < HW) a[rb][j] = *reinterpret_cast<const uint4*>(rp + 8 * j);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rb = 0; rb < WD_RB; ++rb)
+                acc[rb] = Mma16<T>::run(__builtin_bit_cast(s16x8, a[rb][j]), __builtin_bit_cast(s16x8, b[j]), acc[rb]);
+    }
+    float* dst = part + (long long)split * MR * NS;
+    if (cs) {
+#pragma unroll
+        for (int rb = 0; rb < WD_RB; ++rb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = row0 + 32 * rb + acc_row(reg, h);
+                if (r < MR) dst[(long long)r * NS + col] = acc[rb][reg];
+            }
+    }
+}
+
+static WdPlan wd_plan(int64_t N, int64_t Cin, int64_t Cout, int64_t HW) {
+    WdPlan p;
+    p.MR = (int)(Cout >= Cin ? Cout : Cin);
+    p.NS = (int)(Cout >= Cin ? Cin : Cout);
+    p.quads_per_img = (int)cdiv(HW, 64);
+    p.total_quads = (int)(N * p.quads_per_img);
+    const int64_t tiles = cdiv(p.MR, WD_ROWS) * cdiv(p.NS, WD_COLS);
+    int64_t want = 256 / (tiles > 0 ? tiles : 1);   // one 8-wave block per CU ...
+    if (want > p.total_quads / 4) want = p.total_quads / 4;   // ... but at least 4 quads per slab written
+    if (want < 1) want = 1;
+    p.nsplit = (int)want;
+    return p;
+}
+
 struct WgradPlan {
     int stages_per_img, total_stages, nsplit, stages_per_split, MR, NS;
 };
@@ -654,6 +740,19 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
     // out(r, s): r indexes the big operand's channels
     const long long sr = big_is_dy ? ldw : 1, ss = big_is_dy ? 1 : ldw;
     const bool al = aligned_for(dy, x, HW, Elem<T>::is16);
+    if constexpr (Elem<T>::is16) {
+        if (al) {
+            const WdPlan wp = wd_plan(N, Cin, Cout, HW);
+            dim3 grid((unsigned)wp.nsplit, (unsigned)cdiv(wp.MR, WD_ROWS), (unsigned)cdiv(wp.NS, WD_COLS));
+            hipLaunchKernelGGL((pw_wgrad_direct_kernel<T>), grid, dim3(512), 0, st, R, S, ws, wp.MR, wp.NS, (int)HW, wp);
+            int rc = check_launch(name);
+            if (rc) return rc;
+            const long long tot = (long long)wp.MR * wp.NS;
+            hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(256), 0, st, ws, dw, wp.MR,
+                               wp.NS, wp.nsplit, sr, ss);
+            return check_launch(name);
+        }
+    }
     dim3 grid((unsigned)cdiv(p.MR, 64), (unsigned)cdiv(p.NS, 64), (unsigned)p.nsplit);
     if (al)
         hipLaunchKernelGGL((pw_wgrad_kernel<T, true>), grid, dim3(PW_THREADS), 0, st, R, S, ws, p.MR, p.NS, (int)HW,
@@ -697,7 +796,9 @@ OFASR_EXPORT size_t ofasr_pwconv_wgrad_workspace(int64_t N, int64_t Cin, int64_t
     if (N <= 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return 0;
     // the 16-bit and fp32 kernels stage different pixel counts per barrier: size for the larger plan
     const WgradPlan p4 = wgrad_plan(N, Cin, Cout, HW, 4), p2 = wgrad_plan(N, Cin, Cout, HW, 2);
-    const int ns = p4.nsplit > p2.nsplit ? p4.nsplit : p2.nsplit;
+    int ns = p4.nsplit > p2.nsplit ? p4.nsplit : p2.nsplit;
+    const int nd = wd_plan(N, Cin, Cout, HW).nsplit;
+    ns = nd > ns ? nd : ns;
     return (size_t)ns * (size_t)p4.MR * (size_t)p4.NS * sizeof(float);
 }
 
