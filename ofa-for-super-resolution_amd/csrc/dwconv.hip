@@ -299,10 +299,10 @@ struct VecGeom {
 };
 
 // wave = (plane, slab); group g of the wave owns rows [slab*gpw*R + g*R, +R) of that plane
-template <typename T, int K, bool FLIP>
+template <typename T, int K, bool FLIP, bool XF = false>
 __global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restrict__ x, const float* __restrict__ f,
                                                                T* __restrict__ y, int C, int H, int W, VecGeom vg,
-                                                               long long nwaves) {
+                                                               long long nwaves, InputXf xf = InputXf{}) {
     constexpr int PAD = K / 2;
     constexpr int PXL = VecPx<T, K>::N;
     typedef PxIO<T, PXL> IO;
@@ -318,6 +318,12 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restri
     float taps[K * K];
 #pragma unroll
     for (int e = 0; e < K * K; ++e) taps[e] = f[(long long)c * K * K + (FLIP ? (K * K - 1 - e) : e)];
+    float xsc = 1.f, xmu = 0.f, xb = 0.f;            // fused BN + ReLU6 of the input plane (wave-uniform)
+    if constexpr (XF) {
+        xsc = xf.scale[c];
+        xmu = xf.mean[c];
+        xb = fmaf(xmu, xsc, xf.shift[c]);
+    }
 
     const int g = lane / vg.G, gl = lane - g * vg.G;
     const bool live = g < vg.gpw;                    // lanes past the last full group idle (W does not divide 64*PXL)
@@ -351,6 +357,11 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restri
             const int hin = hstart + t;
             float v[PXL], win[PXL + 2 * PAD + 1];
             IO::unpack(raw[u], v);
+            if constexpr (XF) {   // rows outside the image are the convolution's zero padding, not relu6(beta)
+                const bool rv = live && t < niter && hin >= 0 && hin < H;
+#pragma unroll
+                for (int p = 0; p < PXL; ++p) v[p] = rv ? fminf(fmaxf(fmaf(v[p] - xmu, xsc, xb), 0.f), 6.f) : 0.f;
+            }
             raw[u] = load_row(t + K);
             build_window<PXL, PAD>(v, win, lane, has_left, has_right);
 #pragma unroll
@@ -376,10 +387,11 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restri
 }
 
 // wgrad: wave = (plane, slab); partial[wave][i][j] = sum_{h in slab, w} dy[h][w-j+PAD] * x[h+i-PAD][w]
-template <typename T, int K>
+template <typename T, int K, bool XF = false>
 __global__ void __launch_bounds__(64 * DW_WAVES) dw_wgrad_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                      float* __restrict__ part_out, int H, int W,
-                                                                     VecGeom vg, long long nwaves) {
+                                                                     VecGeom vg, long long nwaves, int C = 1,
+                                                                     InputXf xf = InputXf{}) {
     constexpr int PAD = K / 2;
     constexpr int PXL = 4;
     typedef PxIO<T, PXL> IO;
@@ -405,8 +417,25 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_wgrad_vec_kernel(const T* __
     float xr[K][PXL];   // ring of x rows: slot m mod K holds row h0 - PAD + m
     auto load_x = [&](int r) -> raw_t { return (live && r >= 0 && r < H) ? xp[(long long)r * Wq] : IO::zero(); };
     auto load_g = [&](int h) -> raw_t { return (h < h1) ? dp[(long long)h * Wq] : IO::zero(); };
+    float xsc = 1.f, xmu = 0.f, xb = 0.f;   // fused BN + ReLU6 of the x plane (wave-uniform channel)
+    if constexpr (XF) {
+        const int c = (int)(plane % C);
+        xsc = xf.scale[c];
+        xmu = xf.mean[c];
+        xb = fmaf(xmu, xsc, xf.shift[c]);
+    }
+    auto xform = [&](float* v, int r) {   // r = image row of the values; rows outside the image stay zero
+        if constexpr (XF) {
+            const bool rv = live && r >= 0 && r < H;
 #pragma unroll
-    for (int m = 0; m < K - 1; ++m) IO::unpack(load_x(h0 - PAD + m), xr[m]);
+            for (int p = 0; p < PXL; ++p) v[p] = rv ? fminf(fmaxf(fmaf(v[p] - xmu, xsc, xb), 0.f), 6.f) : 0.f;
+        }
+    };
+#pragma unroll
+    for (int m = 0; m < K - 1; ++m) {
+        IO::unpack(load_x(h0 - PAD + m), xr[m]);
+        xform(xr[m], h0 - PAD + m);
+    }
 #pragma unroll
     for (int p = 0; p < PXL; ++p) xr[K - 1][p] = 0.f;
     raw_t rawx[K], rawg[K];
@@ -421,6 +450,7 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_wgrad_vec_kernel(const T* __
             const int h = h0 + base + u;
             float gv[PXL], gwin[PXL + 2 * PAD + 1];
             IO::unpack(rawx[u], xr[(u + K - 1) % K]);   // row h + PAD enters the ring
+            xform(xr[(u + K - 1) % K], h + PAD);
             IO::unpack(rawg[u], gv);
             rawx[u] = load_x(h + K + PAD);
             rawg[u] = load_g(h + K);
@@ -491,16 +521,17 @@ static int wgrad_parts(int64_t N, int64_t C) {
     return (int)want;
 }
 
-template <typename T, bool FLIP>
+template <typename T, bool FLIP, bool XF = false>
 static int launch_conv(const char* name, const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H,
-                       int64_t W, int K, hipStream_t st) {
+                       int64_t W, int K, hipStream_t st, InputXf xf = InputXf{}) {
     {
         VecGeom vg;
 #define OFASR_DWV(KK)                                                                                               \
     if (vec_geom(H, W, (int)sizeof(T), VecPx<T, KK>::N, x, y, vg)) {                                               \
         const long long nwaves = (long long)N * C * vg.nslabs;                                                     \
-        hipLaunchKernelGGL((dw_vec_kernel<T, KK, FLIP>), dim3((unsigned)cdiv(nwaves, DW_WAVES)), dim3(64 * DW_WAVES), \
-                           0, st, (const T*)x, f, (T*)y, (int)C, (int)H, (int)W, vg, nwaves);                      \
+        hipLaunchKernelGGL((dw_vec_kernel<T, KK, FLIP, XF>), dim3((unsigned)cdiv(nwaves, DW_WAVES)),               \
+                           dim3(64 * DW_WAVES), 0, st, (const T*)x, f, (T*)y, (int)C, (int)H, (int)W, vg, nwaves,  \
+                           xf);                                                                                    \
         return check_launch(name);                                                                                 \
     }
         switch (K) {
@@ -510,6 +541,10 @@ static int launch_conv(const char* name, const void* x, const float* f, void* y,
             default: OFASR_DWV(7) break;
         }
 #undef OFASR_DWV
+    }
+    if constexpr (XF) {
+        set_error("%s: fused input transform needs the vector kernel", name);
+        return OFASR_ERR_UNSUPPORTED;
     }
     const int rows_per_chunk = H <= 32 ? (int)H : 32;
     const int nchunks = (int)cdiv(H, rows_per_chunk);
@@ -557,17 +592,17 @@ static int conv_entry(const char* name, const void* x, const float* f, void* y, 
     }
 }
 
-template <typename T>
+template <typename T, bool XF = false>
 static int launch_wgrad(const char* name, const void* dy, const void* x, float* df, int64_t N, int64_t C,
-                        int64_t H, int64_t W, int K, float* ws, hipStream_t st) {
+                        int64_t H, int64_t W, int K, float* ws, hipStream_t st, InputXf xf = InputXf{}) {
     {
         VecGeom vg;
         if (vec_geom(H, W, (int)sizeof(T), 4, dy, x, vg)) {
             const long long nwaves = (long long)N * C * vg.nslabs;
             const unsigned grid = (unsigned)cdiv(nwaves, DW_WAVES);
 #define OFASR_DWWV(KK)                                                                                              \
-    hipLaunchKernelGGL((dw_wgrad_vec_kernel<T, KK>), dim3(grid), dim3(64 * DW_WAVES), 0, st, (const T*)dy, (const T*)x, \
-                       ws, (int)H, (int)W, vg, nwaves)
+    hipLaunchKernelGGL((dw_wgrad_vec_kernel<T, KK, XF>), dim3(grid), dim3(64 * DW_WAVES), 0, st, (const T*)dy,      \
+                       (const T*)x, ws, (int)H, (int)W, vg, nwaves, (int)C, xf)
             switch (K) {
                 case 1: OFASR_DWWV(1); break;
                 case 3: OFASR_DWWV(3); break;
@@ -582,6 +617,10 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
                                (int)N, (int)C, vg.nslabs, K * K);
             return check_launch(name);
         }
+    }
+    if constexpr (XF) {
+        set_error("%s: fused input transform needs the vector kernel", name);
+        return OFASR_ERR_UNSUPPORTED;
     }
     const int nparts = wgrad_parts(N, C);
     const long long units = (long long)C * nparts;
@@ -602,6 +641,42 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
     hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)cdiv(CKK, 256)), dim3(256), 0, st, ws, df, nparts,
                        CKK);
     return check_launch(name);
+}
+
+bool dwconv_xf_supported(const void* x, const void* y, int64_t H, int64_t W, int K, int dtype) {
+    if (dtype != OFASR_F16 && dtype != OFASR_BF16) return false;
+    VecGeom vg;
+    const int pxl = K <= 3 ? 8 : 4;
+    return vec_geom(H, W, 2, pxl, x, y, vg) && vec_geom(H, W, 2, 4, x, y, vg);
+}
+
+int dwconv_fwd_xf(const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H, int64_t W, int K, int dtype,
+                  InputXf xf, void* stream) {
+    const char* name = "dwconv_fwd_xf";
+    int rc = check_conv_args(name, x, f, y, N, C, H, W, K, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(xf.scale && xf.shift && xf.mean, OFASR_ERR_INVALID_ARG, "%s: null transform", name);
+    OFASR_REQUIRE(dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_UNSUPPORTED, "%s: 16-bit only", name);
+    if (N * C * H * W == 0) return OFASR_OK;
+    hipStream_t st = as_stream(stream);
+    if (dtype == OFASR_F16) return launch_conv<f16_t, false, true>(name, x, f, y, N, C, H, W, K, st, xf);
+    return launch_conv<bf16_t, false, true>(name, x, f, y, N, C, H, W, K, st, xf);
+}
+
+int dwconv_wgrad_xf(const void* dy, const void* x, float* df, int64_t N, int64_t C, int64_t H, int64_t W, int K,
+                    int dtype, InputXf xf, void* workspace, size_t workspace_bytes, void* stream) {
+    const char* name = "dwconv_wgrad_xf";
+    int rc = check_conv_args(name, dy, x, df, N, C, H, W, K, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(xf.scale && xf.shift && xf.mean, OFASR_ERR_INVALID_ARG, "%s: null transform", name);
+    OFASR_REQUIRE(dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_UNSUPPORTED, "%s: 16-bit only", name);
+    OFASR_REQUIRE(N * C * H * W > 0, OFASR_ERR_UNSUPPORTED, "%s: empty tensor", name);
+    const size_t need = ofasr_dwconv_wgrad_workspace(N, C, H, W, K);
+    OFASR_REQUIRE(workspace && workspace_bytes >= need, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B",
+                  name, workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    if (dtype == OFASR_F16) return launch_wgrad<f16_t, true>(name, dy, x, df, N, C, H, W, K, (float*)workspace, st, xf);
+    return launch_wgrad<bf16_t, true>(name, dy, x, df, N, C, H, W, K, (float*)workspace, st, xf);
 }
 
 }  // namespace ofasr

@@ -2,7 +2,10 @@
 // DynamicMBConvLayer (+ identity shortcut) forward or backward (see include/ofasr.h).
 //
 // No new arithmetic lives here: it sequences the kernels of pwconv.hip / dwconv.hip / ktransform.hip /
-// bnact.hip on one stream, carving a caller-provided workspace.  The point is host cost: per block the
+// bnact.hip on one stream, carving a caller-provided workspace.  With 16-bit activations and vector-eligible
+// shapes BN1/BN2 + ReLU6 are not separate passes: the depthwise / project kernels (and their weight-gradient
+// kernels) apply scale/shift/clamp to the pre-BN tensor as they read it (InputXf), so the activated mid tensors
+// are never written or re-read.  The point is host cost: per block the
 // Python side makes 1 FFI call per direction instead of ~25 (each with its own autograd node, allocations
 // and ctypes marshalling), which is what bounded the training step once the kernels were fast.
 #include "ofasr_common.h"
@@ -98,6 +101,39 @@ static int bn_forward(const ofasr_mbconv_desc* d, int which, const void* x, cons
                         d->dtype, ws, ws_bytes, stream);
 }
 
+// statistics of one of the block's BNs without the apply pass: mean | invstd | scale | shift (+ running stats);
+// the consumer kernel applies scale/shift + ReLU6 as it reads the tensor (InputXf)
+static int bn_statistics(const ofasr_mbconv_desc* d, int which, const void* x, int64_t C, float* stat_buf, void* ws,
+                         size_t ws_bytes, void* stream) {
+    const int64_t HW = d->H * d->W;
+    StatView sv = stat_view(stat_buf, which, d->mid, d->Cout);
+    const int training = d->bn_training[which];
+    if (training) {
+        int rc = ofasr_bn_stats(x, d->N, C, HW, d->dtype, ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return ofasr_bn_finalize(ws, ofasr_bn_partials(d->N, C), C, (double)d->N * (double)HW, d->gamma[which],
+                             d->beta[which], d->running_mean[which], d->running_var[which], d->bn_momentum[which],
+                             d->bn_eps[which], training, sv.mean, sv.invstd, sv.scale, sv.shift, stream);
+}
+
+static InputXf xf_of(const float* stat_buf, int which, int64_t mid, int64_t cout) {
+    StatView sv = stat_view(const_cast<float*>(stat_buf), which, mid, cout);
+    return InputXf{sv.scale, sv.shift, sv.mean};
+}
+
+// BN1/BN2 + ReLU6 are applied by the consumer's loads (a1, a2 are never written) when the vector depthwise and the
+// aligned 16-bit pointwise kernels apply to the block; forward and backward take the same decision from the
+// descriptor and the (caller-provided) buffer addresses.
+static bool fuse_apply(const ofasr_mbconv_desc* d, const MbSizes& s, const void* act_buf) {
+    const char* a = (const char*)act_buf;
+    const void* y1 = a;
+    const void* y2 = a + 2 * s.mid_elems * s.es;
+    const void* y3 = a + 4 * s.mid_elems * s.es;
+    return dwconv_xf_supported(y1, y2, d->H, d->W, d->K, d->dtype) &&
+           pwconv_xf_supported(y2, y3, d->H * d->W, d->dtype);
+}
+
 }  // namespace ofasr
 
 using namespace ofasr;
@@ -143,6 +179,22 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
     // expand 1x1 -> BN + ReLU6
     rc = ofasr_pwconv_fwd(x, d->w1, d->ldw1, y1, d->N, d->Cin, d->mid, HW, d->dtype, stream);
     if (rc) return rc;
+    if (fuse_apply(d, s, act_buf)) {
+        rc = bn_statistics(d, 0, y1, d->mid, stat_buf, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        rc = ofasr_ktransform_fwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, f, d->mid, stream);
+        if (rc) return rc;
+        rc = dwconv_fwd_xf(y1, f, y2, d->N, d->mid, d->H, d->W, d->K, d->dtype, xf_of(stat_buf, 0, d->mid, d->Cout),
+                           stream);
+        if (rc) return rc;
+        rc = bn_statistics(d, 1, y2, d->mid, stat_buf, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        rc = pwconv_fwd_xf(y2, d->w2, d->ldw2, y3, d->N, d->mid, d->Cout, HW, d->dtype,
+                           xf_of(stat_buf, 1, d->mid, d->Cout), stream);
+        if (rc) return rc;
+        return bn_forward(d, 2, y3, d->residual ? x : nullptr, out, d->Cout, 0, stat_buf, workspace, workspace_bytes,
+                          stream);
+    }
     rc = bn_forward(d, 0, y1, nullptr, a1, d->mid, 1, stat_buf, workspace, workspace_bytes, stream);
     if (rc) return rc;
     // active depthwise filter -> depthwise -> BN + ReLU6
@@ -225,8 +277,16 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     // project 1x1
     rc = ofasr_pwconv_dgrad(t3, d->w2, d->ldw2, tA, d->N, d->mid, d->Cout, HW, d->dtype, stream);
     if (rc) return rc;
-    rc = ofasr_pwconv_wgrad(t3, a2, g->dw2, d->ldw2, d->N, d->mid, d->Cout, HW, d->dtype, workspace, workspace_bytes,
-                            stream);
+    const bool fused = fuse_apply(d, s, act_buf);
+    if (fused) {
+        OFASR_REQUIRE((reinterpret_cast<uintptr_t>(tmp_buf) & 15) == 0, OFASR_ERR_UNSUPPORTED,
+                      "%s: tmp_buf must be 16-byte aligned (the forward pass did not materialise the activations)", name);
+        rc = pwconv_wgrad_xf(t3, y2, g->dw2, d->ldw2, d->N, d->mid, d->Cout, HW, d->dtype,
+                             xf_of(stat_buf, 1, d->mid, d->Cout), workspace, workspace_bytes, stream);
+    } else {
+        rc = ofasr_pwconv_wgrad(t3, a2, g->dw2, d->ldw2, d->N, d->mid, d->Cout, HW, d->dtype, workspace,
+                                workspace_bytes, stream);
+    }
     if (rc) return rc;
     // BN2 + ReLU6 (in place: da2 -> dy2)
     StatView s2 = stat_view(sb, 1, d->mid, d->Cout);
@@ -238,7 +298,11 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     rc = ofasr_dwconv_dgrad(tA, f, tB, d->N, d->mid, d->H, d->W, d->K, d->dtype, stream);
     if (rc) return rc;
     float* dfp = (float*)((char*)workspace + s.scratch);
-    rc = ofasr_dwconv_wgrad(tA, a1, dfp, d->N, d->mid, d->H, d->W, d->K, d->dtype, workspace, s.scratch, stream);
+    if (fused)
+        rc = dwconv_wgrad_xf(tA, y1, dfp, d->N, d->mid, d->H, d->W, d->K, d->dtype, xf_of(stat_buf, 0, d->mid, d->Cout),
+                             workspace, s.scratch, stream);
+    else
+        rc = ofasr_dwconv_wgrad(tA, a1, dfp, d->N, d->mid, d->H, d->W, d->K, d->dtype, workspace, s.scratch, stream);
     if (rc) return rc;
     rc = ofasr_ktransform_bwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, dfp,
                               g->dwdw_max, g->dmats, d->mid, (char*)workspace + s.scratch + s.df_bytes, s.ws_kt + 256,

@@ -85,4 +85,26 @@ template <> struct uint_of<8> { using type = uint64_t; };
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Optional BatchNorm + ReLU6 applied to an operand as a kernel reads it (the composite MB block never materialises
+// the activated tensor): v -> min(max((v - mean[c]) * scale[c] + beta[c], 0), 6) with beta = shift + mean*scale.
+// Zero padding / out-of-range elements stay exactly zero.  All pointers null = plain read.
+struct InputXf {
+    const float* scale;
+    const float* shift;
+    const float* mean;
+};
+
+// internal (not exported) variants used by mbconv.hip; they return OFASR_ERR_UNSUPPORTED (and launch nothing) when
+// the vector / aligned 16-bit kernels that implement the fused read do not apply to the shape.
+bool dwconv_xf_supported(const void* x, const void* y, int64_t H, int64_t W, int K, int dtype);
+int dwconv_fwd_xf(const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H, int64_t W, int K, int dtype,
+                  InputXf xf, void* stream);
+int dwconv_wgrad_xf(const void* dy, const void* x, float* df, int64_t N, int64_t C, int64_t H, int64_t W, int K,
+                    int dtype, InputXf xf, void* workspace, size_t workspace_bytes, void* stream);
+bool pwconv_xf_supported(const void* x, const void* y, int64_t HW, int dtype);
+int pwconv_fwd_xf(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t HW,
+                  int dtype, InputXf xf, void* stream);
+int pwconv_wgrad_xf(const void* dy, const void* x, float* dw, int64_t ldw, int64_t N, int64_t Cin, int64_t Cout,
+                    int64_t HW, int dtype, InputXf xf, void* workspace, size_t workspace_bytes, void* stream);
+
 }  // namespace ofasr

@@ -179,8 +179,26 @@ __device__ __forceinline__ int pos16(int q) {
     return PX == 4 ? (32 * (q & 3) + (q >> 2)) : (64 * (q >> 6) + 32 * (q & 1) + ((q & 63) >> 1));
 }
 
-template <typename T, int PX, bool ALIGNED>
-__device__ __forceinline__ void stage_x_tile(char* Xs, const T* __restrict__ xn, int K, int HW, int k0, int p0) {
+// fused BN + ReLU6 of 8 packed 16-bit values of channel ch (InputXf, ofasr_common.h)
+template <typename T>
+__device__ __forceinline__ uint4 xf_apply8(uint4 v, const InputXf& xf, int ch) {
+    const float sc = xf.scale[ch], mu = xf.mean[ch], b = fmaf(mu, sc, xf.shift[ch]);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        T lo, hi;
+        lo.v = (uint16_t)(w[i] & 0xffffu);
+        hi.v = (uint16_t)(w[i] >> 16);
+        const float a = fminf(fmaxf(fmaf(to_float(lo) - mu, sc, b), 0.f), 6.f);
+        const float c = fminf(fmaxf(fmaf(to_float(hi) - mu, sc, b), 0.f), 6.f);
+        w[i] = pack2<T>(a, c);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <typename T, int PX, bool ALIGNED, bool XF = false>
+__device__ __forceinline__ void stage_x_tile(char* Xs, const T* __restrict__ xn, int K, int HW, int k0, int p0,
+                                             InputXf xf = InputXf{}) {
     const int tid = threadIdx.x;
     if constexpr (Elem<T>::is16) {
         if (ALIGNED) {
@@ -191,7 +209,10 @@ __device__ __forceinline__ void stage_x_tile(char* Xs, const T* __restrict__ xn,
                 const int k = q >> 4, m = q & 15;
                 const int px = p0 + 8 * m;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (k0 + k < K && px < HW) v = *reinterpret_cast<const uint4*>(xn + (long long)(k0 + k) * HW + px);
+                if (k0 + k < K && px < HW) {
+                    v = *reinterpret_cast<const uint4*>(xn + (long long)(k0 + k) * HW + px);
+                    if constexpr (XF) v = xf_apply8<T>(v, xf, k0 + k);
+                }
                 char* row = Xs + k * XROW16;
                 if (PX == 4) {
                     // pixel 8m+i -> position 32*(i&3) + 2m + (i>>2): pairs (i, i+4) are adjacent
@@ -291,9 +312,9 @@ __device__ __forceinline__ void store_px(T* __restrict__ dst, int px, int HW, co
 // reads of the X tile, 16 MFMAs, packed 8/16-byte stores.  ~36 KB LDS and ~100 VGPRs per block keep
 // 4 blocks (16 waves) per CU so loads of one block overlap the MFMA/store phase of the others.
 constexpr int FO_ROWS = 128;
-template <typename T, bool ALIGNED, bool WVEC>
+template <typename T, bool ALIGNED, bool WVEC, bool XF = false>
 __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y,
-                                                               int HW, int tiles_per_img) {
+                                                               int HW, int tiles_per_img, InputXf xf = InputXf{}) {
     __shared__ __attribute__((aligned(16))) char Ws[FO_ROWS * Elem<T>::wrow];
     __shared__ __attribute__((aligned(16))) char Xs[64 * Elem<T>::xrow];
     const int m_base = blockIdx.y * FO_ROWS;
@@ -307,7 +328,7 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restri
     const T* xn = x + (long long)n * wv.K * HW;
     T* yn = y + ((long long)n * wv.M + m_base) * HW;
 
-    stage_x_tile<T, 4, ALIGNED>(Xs, xn, wv.K, HW, 0, p0);
+    stage_x_tile<T, 4, ALIGNED, XF>(Xs, xn, wv.K, HW, 0, p0, xf);
     stage_w_tile<T, FO_ROWS, WVEC>(Ws, wv, m_base, 0);
     __syncthreads();
 
@@ -356,9 +377,10 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restri
 // any K, 64 output rows per grid.y pass.  K is walked in 64-channel chunks: each chunk stages its X
 // tile (HBM) and its [64 x 64] weight chunk (L2) and adds into accumulators that stay in registers.
 // wave w: output row block cb = w&1, pixel half hh = w>>1 (64 pixels, 2 per lane).
-template <typename T, bool ALIGNED, bool WVEC>
+template <typename T, bool ALIGNED, bool WVEC, bool XF = false>
 __global__ void __launch_bounds__(PW_THREADS) pw_fanin_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y,
-                                                              int HW, int tiles_per_img, int kchunks) {
+                                                              int HW, int tiles_per_img, int kchunks,
+                                                              InputXf xf = InputXf{}) {
     __shared__ __attribute__((aligned(16))) char Ws[64 * Elem<T>::wrow];
     __shared__ __attribute__((aligned(16))) char Xs[64 * Elem<T>::xrow];
     const int m_base = blockIdx.y * 64;
@@ -378,7 +400,7 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_kernel(const T* __restric
     const int row = 32 * cb + c;
     for (int kc = 0; kc < kchunks; ++kc) {
         if (kc) __syncthreads();
-        stage_x_tile<T, 2, ALIGNED>(Xs, xn, wv.K, HW, kc * 64, p0);
+        stage_x_tile<T, 2, ALIGNED, XF>(Xs, xn, wv.K, HW, kc * 64, p0, xf);
         stage_w_tile<T, 64, WVEC>(Ws, wv, m_base, kc * 64);
         __syncthreads();
         if constexpr (Elem<T>::is16) {
@@ -576,10 +598,11 @@ struct WdPlan {
     int quads_per_img, total_quads, nsplit, MR, NS;
 };
 
-template <typename T>
+// XF: 0 none, 1 the R operand, 2 the S operand is read through the fused BN + ReLU6
+template <typename T, int XF = 0>
 __global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restrict__ R, const T* __restrict__ S,
                                                               float* __restrict__ part, int MR, int NS, int HW,
-                                                              WdPlan wp) {
+                                                              WdPlan wp, InputXf xf = InputXf{}) {
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wr = wave & 3, wc = wave >> 2;
@@ -605,7 +628,10 @@ __global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             b[j] = make_uint4(0, 0, 0, 0);
-            if (cs && px + 8 * j < HW) b[j] = *reinterpret_cast<const uint4*>(sp + 8 * j);
+            if (cs && px + 8 * j < HW) {
+                b[j] = *reinterpret_cast<const uint4*>(sp + 8 * j);
+                if constexpr (XF == 2) b[j] = xf_apply8<T>(b[j], xf, col);
+            }
         }
 #pragma unroll
         for (int rb = 0; rb < WD_RB; ++rb) {
@@ -613,7 +639,10 @@ __global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restric
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 a[rb][j] = make_uint4(0, 0, 0, 0);
-                if (rs[rb] && px + 8 * j < HW) a[rb][j] = *reinterpret_cast<const uint4*>(rp + 8 * j);
+                if (rs[rb] && px + 8 * j < HW) {
+                    a[rb][j] = *reinterpret_cast<const uint4*>(rp + 8 * j);
+                    if constexpr (XF == 1) a[rb][j] = xf_apply8<T>(a[rb][j], xf, row0 + 32 * rb + c);
+                }
             }
         }
 #pragma unroll
@@ -675,22 +704,23 @@ static bool aligned_for(const void* a, const void* b, int64_t HW, bool is16) {
     return (bits & 15) == 0 && (HW % (is16 ? 8 : 4)) == 0;
 }
 
-template <typename T, bool AL, bool WV>
+template <typename T, bool AL, bool WV, bool XF = false>
 static void launch_gemm_v(const void* x, WView wv, void* y, int64_t HW, int tiles_per_img, int total_tiles,
-                          hipStream_t st) {
+                          hipStream_t st, InputXf xf = InputXf{}) {
     if (wv.K <= 64) {
         dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, FO_ROWS));
-        hipLaunchKernelGGL((pw_fanout_kernel<T, AL, WV>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
-                           (int)HW, tiles_per_img);
+        hipLaunchKernelGGL((pw_fanout_kernel<T, AL, WV, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
+                           (int)HW, tiles_per_img, xf);
     } else {
         dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, 64));
-        hipLaunchKernelGGL((pw_fanin_kernel<T, AL, WV>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
-                           (int)HW, tiles_per_img, (int)cdiv(wv.K, 64));
+        hipLaunchKernelGGL((pw_fanin_kernel<T, AL, WV, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
+                           (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf);
     }
 }
 
-template <typename T>
-static int launch_gemm(const char* name, const void* x, WView wv, void* y, int64_t N, int64_t HW, hipStream_t st) {
+template <typename T, bool XF = false>
+static int launch_gemm(const char* name, const void* x, WView wv, void* y, int64_t N, int64_t HW, hipStream_t st,
+                       InputXf xf = InputXf{}) {
     constexpr bool is16 = Elem<T>::is16;
     const bool al = aligned_for(x, y, HW, is16);
     const long long ld = wv.sk == 1 ? wv.sm : wv.sk;
@@ -699,6 +729,12 @@ static int launch_gemm(const char* name, const void* x, WView wv, void* y, int64
     const int64_t total64 = N * tiles_per_img;
     OFASR_REQUIRE(total64 <= INT32_MAX, OFASR_ERR_UNSUPPORTED, "%s: too many pixel tiles", name);
     const int total_tiles = (int)total64;
+    if constexpr (XF) {
+        OFASR_REQUIRE(al && is16, OFASR_ERR_UNSUPPORTED, "%s: fused input transform needs aligned 16-bit tensors", name);
+        if (wvec) launch_gemm_v<T, true, true, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, xf);
+        else launch_gemm_v<T, true, false, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, xf);
+        return check_launch(name);
+    }
     if (al && wvec) launch_gemm_v<T, true, true>(x, wv, y, HW, tiles_per_img, total_tiles, st);
     else if (al) launch_gemm_v<T, true, false>(x, wv, y, HW, tiles_per_img, total_tiles, st);
     else if (wvec) launch_gemm_v<T, false, true>(x, wv, y, HW, tiles_per_img, total_tiles, st);
@@ -730,9 +766,9 @@ static int check_pw_args(const char* name, const void* a, const void* b, const v
     return OFASR_OK;
 }
 
-template <typename T>
+template <typename T, bool XF = false>
 static int launch_wgrad(const char* name, const void* dy, const void* x, float* dw, int64_t ldw, int64_t N, int64_t Cin,
-                        int64_t Cout, int64_t HW, float* ws, hipStream_t st) {
+                        int64_t Cout, int64_t HW, float* ws, hipStream_t st, InputXf xf = InputXf{}) {
     const WgradPlan p = wgrad_plan(N, Cin, Cout, HW, WgStage<T>::SUB);
     const bool big_is_dy = Cout >= Cin;
     const T* R = (const T*)(big_is_dy ? dy : x);
@@ -744,7 +780,17 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
         if (al) {
             const WdPlan wp = wd_plan(N, Cin, Cout, HW);
             dim3 grid((unsigned)wp.nsplit, (unsigned)cdiv(wp.MR, WD_ROWS), (unsigned)cdiv(wp.NS, WD_COLS));
-            hipLaunchKernelGGL((pw_wgrad_direct_kernel<T>), grid, dim3(512), 0, st, R, S, ws, wp.MR, wp.NS, (int)HW, wp);
+            if constexpr (XF) {
+                if (big_is_dy)   // x is the S operand
+                    hipLaunchKernelGGL((pw_wgrad_direct_kernel<T, 2>), grid, dim3(512), 0, st, R, S, ws, wp.MR, wp.NS,
+                                       (int)HW, wp, xf);
+                else
+                    hipLaunchKernelGGL((pw_wgrad_direct_kernel<T, 1>), grid, dim3(512), 0, st, R, S, ws, wp.MR, wp.NS,
+                                       (int)HW, wp, xf);
+            } else {
+                hipLaunchKernelGGL((pw_wgrad_direct_kernel<T>), grid, dim3(512), 0, st, R, S, ws, wp.MR, wp.NS, (int)HW,
+                                   wp);
+            }
             int rc = check_launch(name);
             if (rc) return rc;
             const long long tot = (long long)wp.MR * wp.NS;
@@ -752,6 +798,10 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
                                wp.NS, wp.nsplit, sr, ss);
             return check_launch(name);
         }
+    }
+    if constexpr (XF) {
+        set_error("%s: fused input transform needs the aligned 16-bit kernel", name);
+        return OFASR_ERR_UNSUPPORTED;
     }
     dim3 grid((unsigned)cdiv(p.MR, 64), (unsigned)cdiv(p.NS, 64), (unsigned)p.nsplit);
     if (al)
@@ -766,6 +816,41 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
     hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(256), 0, st, ws, dw, p.MR, p.NS,
                        p.nsplit, sr, ss);
     return check_launch(name);
+}
+
+bool pwconv_xf_supported(const void* x, const void* y, int64_t HW, int dtype) {
+    return (dtype == OFASR_F16 || dtype == OFASR_BF16) && aligned_for(x, y, HW, true);
+}
+
+int pwconv_fwd_xf(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t HW,
+                  int dtype, InputXf xf, void* stream) {
+    const char* name = "pwconv_fwd_xf";
+    int rc = check_pw_args(name, x, w, y, ldw, N, Cin, Cout, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(xf.scale && xf.shift && xf.mean, OFASR_ERR_INVALID_ARG, "%s: null transform", name);
+    OFASR_REQUIRE(dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_UNSUPPORTED, "%s: 16-bit only", name);
+    if (N * HW == 0) return OFASR_OK;
+    WView wv{w, ldw, 1, (int)Cout, (int)Cin};
+    hipStream_t st = as_stream(stream);
+    if (dtype == OFASR_F16) return launch_gemm<f16_t, true>(name, x, wv, y, N, HW, st, xf);
+    return launch_gemm<bf16_t, true>(name, x, wv, y, N, HW, st, xf);
+}
+
+int pwconv_wgrad_xf(const void* dy, const void* x, float* dw, int64_t ldw, int64_t N, int64_t Cin, int64_t Cout,
+                    int64_t HW, int dtype, InputXf xf, void* workspace, size_t workspace_bytes, void* stream) {
+    const char* name = "pwconv_wgrad_xf";
+    int rc = check_pw_args(name, dy, x, dw, ldw, N, Cin, Cout, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(xf.scale && xf.shift && xf.mean, OFASR_ERR_INVALID_ARG, "%s: null transform", name);
+    OFASR_REQUIRE(dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_UNSUPPORTED, "%s: 16-bit only", name);
+    OFASR_REQUIRE(N * HW > 0, OFASR_ERR_UNSUPPORTED, "%s: empty tensor", name);
+    const size_t need = ofasr_pwconv_wgrad_workspace(N, Cin, Cout, HW);
+    OFASR_REQUIRE(workspace && workspace_bytes >= need, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B",
+                  name, workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    if (dtype == OFASR_F16)
+        return launch_wgrad<f16_t, true>(name, dy, x, dw, ldw, N, Cin, Cout, HW, (float*)workspace, st, xf);
+    return launch_wgrad<bf16_t, true>(name, dy, x, dw, ldw, N, Cin, Cout, HW, (float*)workspace, st, xf);
 }
 
 }  // namespace ofasr

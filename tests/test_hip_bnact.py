@@ -141,50 +141,66 @@ def test_fused_and_modular_paths_agree():
 
 
 def test_composite_block_matches_per_op_path():
-    """ofasr_mbconv_fwd/_bwd (one FFI call per block and direction) vs the per-op autograd Functions: same kernels
-    in the same order, so outputs and every gradient agree to fp32 round-off."""
+    """ofasr_mbconv_fwd/_bwd (one FFI call per block and direction) vs the per-op autograd Functions.  fp32: same kernels
+    in the same order, outputs and every gradient agree to round-off.  16-bit: the composite call applies BN1/BN2 + ReLU6
+    inside the consumer kernels from the pre-BN tensor (the activated tensor is never rounded to 16 bits), so it is a
+    different -- not a worse -- 16-bit realisation: both are measured against the fp32 result in the L2 norm
+    (tools/chk_fused.py prints the numbers: 4.7 % vs 4.6 % on dx in train mode, 0.4 % on y)."""
     ops = amd("ops")
     dop = amd("elastic_nn.modules.dynamic_op")
     dl = amd("elastic_nn.modules.dynamic_layers")
     blk = amd("imagenet_codebase.networks")
     layers = amd("layers")
     dop.DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = 1
-    for dtype in (torch.float32, torch.bfloat16):
-        for (k, e, train) in [(7, 6, True), (5, 4, True), (3, 3, False)]:
-            torch.manual_seed(3)
-            layer = dl.DynamicMBConvLayer([64], [64], [3, 5, 7], [3, 4, 6])
-            block = blk.MobileInvertedResidualBlock(layer, layers.IdentityLayer([64], [64])).to(DEV).train(train)
-            for m in block.modules():
-                if isinstance(m, torch.nn.BatchNorm2d):
-                    m.running_mean.uniform_(-0.2, 0.2)
-                    m.running_var.uniform_(0.5, 1.5)
-                    m.weight.data.uniform_(0.5, 1.5)
-            layer.depth_conv.conv.__getattr__("7to5_matrix").data.add_(0.1 * torch.randn(25, 25, device=DEV))
-            layer.active_kernel_size, layer.active_expand_ratio = k, e
-            x0 = torch.randn(2, 64, 16, 24, device=DEV).to(dtype)
-            dy = torch.randn(2, 64, 16, 24, device=DEV).to(dtype)
-            sd = {kk: v.clone() for kk, v in block.state_dict().items()}
-            res = []
-            for composite in (True, False):
-                block.load_state_dict(sd)
-                block.zero_grad()
-                ops.FUSED_BLOCK = composite
-                try:
-                    x = x0.clone().requires_grad_(True)
-                    y = block(x)
-                    y.backward(dy)
-                finally:
-                    ops.FUSED_BLOCK = True
-                res.append((y.detach().float(), x.grad.float(),
-                            {n: (None if p.grad is None else p.grad.clone()) for n, p in block.named_parameters()},
-                            {n: b.clone() for n, b in block.named_buffers()}))
-            (ya, xa, ga, ba), (yb, xb, gb, bb) = res
-            tol = 1e-5 if dtype == torch.float32 else 2e-2
-            assert float((ya - yb).abs().max()) <= tol * max(1.0, float(yb.abs().max()))
-            assert float((xa - xb).abs().max()) <= tol * max(1.0, float(xb.abs().max()))
-            for n in ga:
-                assert (ga[n] is None) == (gb[n] is None), n
-                if ga[n] is not None:
-                    assert float((ga[n] - gb[n]).abs().max()) <= tol * max(1e-3, float(gb[n].abs().max())), n
-            for n in ba:
-                assert torch.allclose(ba[n].float(), bb[n].float(), rtol=1e-5, atol=1e-6), n
+
+    def run(block, sd, x0, dy, dtype, composite):
+        block.load_state_dict(sd)
+        block.zero_grad()
+        ops.FUSED_BLOCK = composite
+        try:
+            x = x0.to(dtype).clone().requires_grad_(True)
+            y = block(x)
+            y.backward(dy.to(dtype))
+        finally:
+            ops.FUSED_BLOCK = True
+        return (y.detach().float(), x.grad.float(),
+                {n: (None if p.grad is None else p.grad.clone()) for n, p in block.named_parameters()},
+                {n: b.clone() for n, b in block.named_buffers()})
+
+    for (k, e, train) in [(7, 6, True), (5, 4, True), (3, 3, False)]:
+        torch.manual_seed(3)
+        layer = dl.DynamicMBConvLayer([64], [64], [3, 5, 7], [3, 4, 6])
+        block = blk.MobileInvertedResidualBlock(layer, layers.IdentityLayer([64], [64])).to(DEV).train(train)
+        for m in block.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.5, 1.5)
+        layer.depth_conv.conv.__getattr__("7to5_matrix").data.add_(0.1 * torch.randn(25, 25, device=DEV))
+        layer.active_kernel_size, layer.active_expand_ratio = k, e
+        x0 = torch.randn(2, 64, 16, 24, device=DEV).bfloat16().float()
+        dy = torch.randn(2, 64, 16, 24, device=DEV).bfloat16().float()
+        sd = {kk: v.clone() for kk, v in block.state_dict().items()}
+        (ya, xa, ga, ba) = run(block, sd, x0, dy, torch.float32, True)
+        (yb, xb, gb, bb) = run(block, sd, x0, dy, torch.float32, False)
+        tol = 1e-5
+        assert float((ya - yb).abs().max()) <= tol * max(1.0, float(yb.abs().max()))
+        assert float((xa - xb).abs().max()) <= tol * max(1.0, float(xb.abs().max()))
+        for n in ga:
+            assert (ga[n] is None) == (gb[n] is None), n
+            if ga[n] is not None:
+                assert float((ga[n] - gb[n]).abs().max()) <= tol * max(1e-3, float(gb[n].abs().max())), n
+        for n in ba:
+            assert torch.allclose(ba[n].float(), bb[n].float(), rtol=1e-5, atol=1e-6), n
+        # 16-bit: composite (fused BN apply) and per-op, each against the fp32 per-op result
+        (yc, xc, gc, bc) = run(block, sd, x0, dy, torch.bfloat16, True)
+        (yd, xd, gd, bd) = run(block, sd, x0, dy, torch.bfloat16, False)
+        rel = lambda a, r: float((a - r).norm()) / max(float(r.norm()), 1e-12)
+        assert rel(yc, yb) <= 1.25 * rel(yd, yb) + 1e-3 and rel(yc, yb) <= 1e-2
+        assert rel(xc, xb) <= 1.25 * rel(xd, xb) + 1e-3
+        for n in gb:
+            assert (gc[n] is None) == (gb[n] is None), n
+            if gb[n] is not None:
+                assert rel(gc[n], gb[n]) <= 1.25 * rel(gd[n], gb[n]) + 2e-3, n
+        for n in bb:
+            assert torch.allclose(bc[n].float(), bb[n].float(), rtol=2e-2, atol=2e-3), n
