@@ -138,7 +138,13 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(const double* __restric
                                                          float* __restrict__ running_var, double momentum, double eps,
                                                          int training, float* __restrict__ mean_out,
                                                          float* __restrict__ invstd_out, float* __restrict__ scale,
-                                                         float* __restrict__ shift) {
+                                                         float* __restrict__ shift, int64_t* k0 = nullptr,
+                                                         int64_t* k1 = nullptr, int64_t* k2 = nullptr) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // num_batches_tracked of the composite block's BNs ride along
+        if (k0) *k0 += 1;
+        if (k1) *k1 += 1;
+        if (k2) *k2 += 1;
+    }
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= C) return;
     double mean, var;
@@ -465,6 +471,22 @@ OFASR_EXPORT int ofasr_bn_finalize(const void* workspace, int64_t n_partials, in
                        momentum, eps, training, mean, invstd, scale, shift);
     return check_launch(name);
 }
+
+namespace ofasr {
+int bn_finalize_bump(const void* workspace, int64_t n_partials, int64_t C, double count, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, double momentum, double eps,
+                     int training, float* mean, float* invstd, float* scale, float* shift, int64_t* k0, int64_t* k1,
+                     int64_t* k2, void* stream) {
+    const char* name = "bn_finalize_bump";
+    OFASR_REQUIRE(C > 0 && mean && invstd && scale && shift, OFASR_ERR_INVALID_ARG, "%s: null output or C<=0", name);
+    OFASR_REQUIRE(training ? (workspace != nullptr && n_partials > 0 && count > 0) : (running_mean && running_var),
+                  OFASR_ERR_INVALID_ARG, "%s: missing statistics source", name);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, as_stream(stream),
+                       (const double*)workspace, (int)n_partials, (int)C, count, gamma, beta, running_mean, running_var,
+                       momentum, eps, training, mean, invstd, scale, shift, k0, k1, k2);
+    return check_launch(name);
+}
+}  // namespace ofasr
 
 OFASR_EXPORT int ofasr_bn_partials(int64_t N, int64_t C) { return (N > 0 && C > 0) ? bn_parts(N, C) : 0; }
 

@@ -75,12 +75,6 @@ __global__ void bump_counters_kernel(int64_t* a, int64_t* b, int64_t* c) {
     }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) add_inplace_kernel(T* __restrict__ a, const T* __restrict__ b, long long n) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        a[i] = from_float<T>(to_float(a[i]) + to_float(b[i]));
-}
-
 struct StatView {
     float *mean, *invstd, *scale, *shift;
 };
@@ -104,7 +98,7 @@ static int bn_forward(const ofasr_mbconv_desc* d, int which, const void* x, cons
 // statistics of one of the block's BNs without the apply pass: mean | invstd | scale | shift (+ running stats);
 // the consumer kernel applies scale/shift + ReLU6 as it reads the tensor (InputXf)
 static int bn_statistics(const ofasr_mbconv_desc* d, int which, const void* x, int64_t C, float* stat_buf, void* ws,
-                         size_t ws_bytes, void* stream) {
+                         size_t ws_bytes, void* stream, bool bump = false) {
     const int64_t HW = d->H * d->W;
     StatView sv = stat_view(stat_buf, which, d->mid, d->Cout);
     const int training = d->bn_training[which];
@@ -112,9 +106,12 @@ static int bn_statistics(const ofasr_mbconv_desc* d, int which, const void* x, i
         int rc = ofasr_bn_stats(x, d->N, C, HW, d->dtype, ws, ws_bytes, stream);
         if (rc) return rc;
     }
-    return ofasr_bn_finalize(ws, ofasr_bn_partials(d->N, C), C, (double)d->N * (double)HW, d->gamma[which],
-                             d->beta[which], d->running_mean[which], d->running_var[which], d->bn_momentum[which],
-                             d->bn_eps[which], training, sv.mean, sv.invstd, sv.scale, sv.shift, stream);
+    int64_t* k[3] = {nullptr, nullptr, nullptr};
+    if (bump)
+        for (int i = 0; i < 3; ++i) k[i] = d->bn_training[i] ? d->num_batches_tracked[i] : nullptr;
+    return bn_finalize_bump(ws, ofasr_bn_partials(d->N, C), C, (double)d->N * (double)HW, d->gamma[which],
+                            d->beta[which], d->running_mean[which], d->running_var[which], d->bn_momentum[which],
+                            d->bn_eps[which], training, sv.mean, sv.invstd, sv.scale, sv.shift, k[0], k[1], k[2], stream);
 }
 
 static InputXf xf_of(const float* stat_buf, int which, int64_t mid, int64_t cout) {
@@ -167,8 +164,9 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
     void* out = a + (4 * s.mid_elems + s.out_elems) * s.es;
     float* f = stat_buf + 8 * d->mid + 4 * d->Cout;
 
-    if ((d->bn_training[0] && d->num_batches_tracked[0]) || (d->bn_training[1] && d->num_batches_tracked[1]) ||
-        (d->bn_training[2] && d->num_batches_tracked[2])) {
+    const bool fused = fuse_apply(d, s, act_buf);
+    if (!fused && ((d->bn_training[0] && d->num_batches_tracked[0]) || (d->bn_training[1] && d->num_batches_tracked[1]) ||
+                   (d->bn_training[2] && d->num_batches_tracked[2]))) {
         hipLaunchKernelGGL(bump_counters_kernel, dim3(1), dim3(64), 0, as_stream(stream),
                            d->bn_training[0] ? d->num_batches_tracked[0] : nullptr,
                            d->bn_training[1] ? d->num_batches_tracked[1] : nullptr,
@@ -179,8 +177,8 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
     // expand 1x1 -> BN + ReLU6
     rc = ofasr_pwconv_fwd(x, d->w1, d->ldw1, y1, d->N, d->Cin, d->mid, HW, d->dtype, stream);
     if (rc) return rc;
-    if (fuse_apply(d, s, act_buf)) {
-        rc = bn_statistics(d, 0, y1, d->mid, stat_buf, workspace, workspace_bytes, stream);
+    if (fused) {
+        rc = bn_statistics(d, 0, y1, d->mid, stat_buf, workspace, workspace_bytes, stream, true);
         if (rc) return rc;
         rc = ofasr_ktransform_fwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, f, d->mid, stream);
         if (rc) return rc;
@@ -314,21 +312,13 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
                           g->dbeta[0], d->N, d->mid, HW, 1, d->bn_training[0], d->dtype, workspace, workspace_bytes,
                           stream);
     if (rc) return rc;
-    // expand 1x1
-    rc = ofasr_pwconv_dgrad(tB, d->w1, d->ldw1, dx, d->N, d->Cin, d->mid, HW, d->dtype, stream);
+    // expand 1x1; x also feeds the identity shortcut, whose gradient (dout) is added in the dgrad epilogue
+    if (d->residual)
+        rc = pwconv_dgrad_add(tB, d->w1, d->ldw1, dx, dout, d->N, d->Cin, d->mid, HW, d->dtype, stream);
+    else
+        rc = ofasr_pwconv_dgrad(tB, d->w1, d->ldw1, dx, d->N, d->Cin, d->mid, HW, d->dtype, stream);
     if (rc) return rc;
     rc = ofasr_pwconv_wgrad(tB, x, g->dw1, d->ldw1, d->N, d->Cin, d->mid, HW, d->dtype, workspace, workspace_bytes,
                             stream);
-    if (rc) return rc;
-    if (d->residual) {   // x also feeds the shortcut: its gradient is dout
-        const long long n = (long long)(d->N * d->Cin * HW);
-        const unsigned grid = (unsigned)(cdiv(n, 256 * 8) < 4096 ? cdiv(n, 256 * 8) : 4096);
-        switch (d->dtype) {
-            case OFASR_F32: hipLaunchKernelGGL((add_inplace_kernel<float>), dim3(grid), dim3(256), 0, st, (float*)dx, (const float*)dout, n); break;
-            case OFASR_F16: hipLaunchKernelGGL((add_inplace_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (f16_t*)dx, (const f16_t*)dout, n); break;
-            default: hipLaunchKernelGGL((add_inplace_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (bf16_t*)dx, (const bf16_t*)dout, n); break;
-        }
-        rc = check_launch(name);
-    }
     return rc;
 }

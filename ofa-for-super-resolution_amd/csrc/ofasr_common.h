@@ -101,6 +101,14 @@ int dwconv_fwd_xf(const void* x, const float* f, void* y, int64_t N, int64_t C, 
                   InputXf xf, void* stream);
 int dwconv_wgrad_xf(const void* dy, const void* x, float* df, int64_t N, int64_t C, int64_t H, int64_t W, int K,
                     int dtype, InputXf xf, void* workspace, size_t workspace_bytes, void* stream);
+// ofasr_bn_finalize that also bumps up to three num_batches_tracked counters (thread 0)
+int bn_finalize_bump(const void* workspace, int64_t n_partials, int64_t C, double count, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, double momentum, double eps,
+                     int training, float* mean, float* invstd, float* scale, float* shift, int64_t* k0, int64_t* k1,
+                     int64_t* k2, void* stream);
+// dx = W^T dy + addend (the identity shortcut's gradient joins in the epilogue of the expand conv's input gradient)
+int pwconv_dgrad_add(const void* dy, const float* w, int64_t ldw, void* dx, const void* addend, int64_t N, int64_t Cin,
+                     int64_t Cout, int64_t HW, int dtype, void* stream);
 bool pwconv_xf_supported(const void* x, const void* y, int64_t HW, int dtype);
 int pwconv_fwd_xf(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t HW,
                   int dtype, InputXf xf, void* stream);

@@ -306,6 +306,40 @@ __device__ __forceinline__ void store_px(T* __restrict__ dst, int px, int HW, co
     }
 }
 
+// v[t] += addend[px + t] (the residual / shortcut gradient accumulated in the epilogue, one rounding on store)
+template <typename T, int PX, bool ALIGNED>
+__device__ __forceinline__ void add_px(const T* __restrict__ src, int px, int HW, float* v) {
+    if (ALIGNED) {
+        if (px < HW) {
+            if constexpr (Elem<T>::is16) {
+                uint32_t w[PX / 2];
+                if (PX == 4) {
+                    const uint2 u = *reinterpret_cast<const uint2*>(src + px);
+                    w[0] = u.x;
+                    w[PX / 2 - 1] = u.y;
+                } else {
+                    w[0] = *reinterpret_cast<const uint32_t*>(src + px);
+                }
+#pragma unroll
+                for (int i = 0; i < PX / 2; ++i) {
+                    T lo, hi;
+                    lo.v = (uint16_t)(w[i] & 0xffffu);
+                    hi.v = (uint16_t)(w[i] >> 16);
+                    v[2 * i] += to_float(lo);
+                    v[2 * i + 1] += to_float(hi);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < PX; ++t) v[t] += to_float(src[px + t]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < PX; ++t)
+            if (px + t < HW) v[t] += to_float(src[px + t]);
+    }
+}
+
 // ------------------------------------------------------------------------------------ fan-out
 // K <= 64.  One block = one 128-pixel tile x one 128-row slab of outputs (grid.y); wave w owns output
 // row block w of the slab: A (weights) from the swizzled LDS operand tile, B (pixels) by transposing
@@ -314,7 +348,8 @@ __device__ __forceinline__ void store_px(T* __restrict__ dst, int px, int HW, co
 constexpr int FO_ROWS = 128;
 template <typename T, bool ALIGNED, bool WVEC, bool XF = false>
 __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y,
-                                                               int HW, int tiles_per_img, InputXf xf = InputXf{}) {
+                                                               int HW, int tiles_per_img, InputXf xf = InputXf{},
+                                                               const T* __restrict__ addend = nullptr) {
     __shared__ __attribute__((aligned(16))) char Ws[FO_ROWS * Elem<T>::wrow];
     __shared__ __attribute__((aligned(16))) char Xs[64 * Elem<T>::xrow];
     const int m_base = blockIdx.y * FO_ROWS;
@@ -367,7 +402,9 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restri
     for (int reg = 0; reg < 16; ++reg) {
         const int r = 32 * cb + acc_row(reg, h);
         if (r < mloc) {
-            const float v[4] = {acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]};
+            float v[4] = {acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]};
+            if (addend)
+                add_px<T, 4, ALIGNED>(addend + ((long long)n * wv.M + m_base + r) * HW, p0 + 4 * c, HW, v);
             store_px<T, 4, ALIGNED>(yn + (long long)r * HW, p0 + 4 * c, HW, v);
         }
     }
@@ -380,7 +417,8 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restri
 template <typename T, bool ALIGNED, bool WVEC, bool XF = false>
 __global__ void __launch_bounds__(PW_THREADS) pw_fanin_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y,
                                                               int HW, int tiles_per_img, int kchunks,
-                                                              InputXf xf = InputXf{}) {
+                                                              InputXf xf = InputXf{},
+                                                              const T* __restrict__ addend = nullptr) {
     __shared__ __attribute__((aligned(16))) char Ws[64 * Elem<T>::wrow];
     __shared__ __attribute__((aligned(16))) char Xs[64 * Elem<T>::xrow];
     const int m_base = blockIdx.y * 64;
@@ -431,7 +469,9 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_kernel(const T* __restric
     for (int reg = 0; reg < 16; ++reg) {
         const int r = 32 * cb + acc_row(reg, h);
         if (r < mloc) {
-            const float v[2] = {acc[0][reg], acc[1][reg]};
+            float v[2] = {acc[0][reg], acc[1][reg]};
+            if (addend)
+                add_px<T, 2, ALIGNED>(addend + ((long long)n * wv.M + m_base + r) * HW, p0 + 64 * hh + 2 * c, HW, v);
             store_px<T, 2, ALIGNED>(yn + (long long)r * HW, p0 + 64 * hh + 2 * c, HW, v);
         }
     }
@@ -557,28 +597,32 @@ __global__ void __launch_bounds__(PW_THREADS) pw_wgrad_kernel(const T* __restric
     }
 }
 
-// dw[r*sr + s*ss] = sum_z part[z][r][s]: 64 outputs x 4 z-lanes per block, z-lane partial sums combined through
-// LDS in a fixed order (deterministic)
-__global__ void __launch_bounds__(256) pw_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                              int MR, int NS, int nsplit, long long sr, long long ss) {
-    __shared__ float red[4][64];
+// dw[r*sr + s*ss] = sum_z part[z][r][s]: 64 outputs x 16 z-lanes per block (each z-lane sums every 16th slab with 4
+// independent loads in flight), z-lane partial sums combined through LDS in a fixed order (deterministic)
+constexpr int WR_ZL = 16;
+__global__ void __launch_bounds__(64 * WR_ZL) pw_wgrad_reduce_kernel(const float* __restrict__ part,
+                                                                     float* __restrict__ dw, int MR, int NS, int nsplit,
+                                                                     long long sr, long long ss) {
+    __shared__ float red[WR_ZL][64];
     const long long tot = (long long)MR * NS;
     const long long idx = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
     const int zl = threadIdx.x >> 6;
     float a = 0.f;
     if (idx < tot) {
         int z = zl;
-        for (; z + 12 < nsplit; z += 16) {   // 4 independent loads in flight
-            const float v0 = part[(long long)z * tot + idx], v1 = part[(long long)(z + 4) * tot + idx];
-            const float v2 = part[(long long)(z + 8) * tot + idx], v3 = part[(long long)(z + 12) * tot + idx];
+        for (; z + 3 * WR_ZL < nsplit; z += 4 * WR_ZL) {
+            const float v0 = part[(long long)z * tot + idx], v1 = part[(long long)(z + WR_ZL) * tot + idx];
+            const float v2 = part[(long long)(z + 2 * WR_ZL) * tot + idx], v3 = part[(long long)(z + 3 * WR_ZL) * tot + idx];
             a += (v0 + v1) + (v2 + v3);
         }
-        for (; z < nsplit; z += 4) a += part[(long long)z * tot + idx];
+        for (; z < nsplit; z += WR_ZL) a += part[(long long)z * tot + idx];
     }
     red[zl][threadIdx.x & 63] = a;
     __syncthreads();
     if (zl == 0 && idx < tot) {
-        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < WR_ZL; ++i) t += red[i][threadIdx.x];
         const long long r = idx / NS, sx = idx - r * NS;
         dw[r * sr + sx * ss] = t;
     }
@@ -706,21 +750,21 @@ static bool aligned_for(const void* a, const void* b, int64_t HW, bool is16) {
 
 template <typename T, bool AL, bool WV, bool XF = false>
 static void launch_gemm_v(const void* x, WView wv, void* y, int64_t HW, int tiles_per_img, int total_tiles,
-                          hipStream_t st, InputXf xf = InputXf{}) {
+                          hipStream_t st, InputXf xf = InputXf{}, const void* addend = nullptr) {
     if (wv.K <= 64) {
         dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, FO_ROWS));
         hipLaunchKernelGGL((pw_fanout_kernel<T, AL, WV, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
-                           (int)HW, tiles_per_img, xf);
+                           (int)HW, tiles_per_img, xf, (const T*)addend);
     } else {
         dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, 64));
         hipLaunchKernelGGL((pw_fanin_kernel<T, AL, WV, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
-                           (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf);
+                           (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf, (const T*)addend);
     }
 }
 
 template <typename T, bool XF = false>
 static int launch_gemm(const char* name, const void* x, WView wv, void* y, int64_t N, int64_t HW, hipStream_t st,
-                       InputXf xf = InputXf{}) {
+                       InputXf xf = InputXf{}, const void* addend = nullptr) {
     constexpr bool is16 = Elem<T>::is16;
     const bool al = aligned_for(x, y, HW, is16);
     const long long ld = wv.sk == 1 ? wv.sm : wv.sk;
@@ -735,20 +779,21 @@ static int launch_gemm(const char* name, const void* x, WView wv, void* y, int64
         else launch_gemm_v<T, true, false, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, xf);
         return check_launch(name);
     }
-    if (al && wvec) launch_gemm_v<T, true, true>(x, wv, y, HW, tiles_per_img, total_tiles, st);
-    else if (al) launch_gemm_v<T, true, false>(x, wv, y, HW, tiles_per_img, total_tiles, st);
-    else if (wvec) launch_gemm_v<T, false, true>(x, wv, y, HW, tiles_per_img, total_tiles, st);
-    else launch_gemm_v<T, false, false>(x, wv, y, HW, tiles_per_img, total_tiles, st);
+    const bool al2 = al && (addend == nullptr || (reinterpret_cast<uintptr_t>(addend) & 15) == 0);
+    if (al2 && wvec) launch_gemm_v<T, true, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, InputXf{}, addend);
+    else if (al2) launch_gemm_v<T, true, false>(x, wv, y, HW, tiles_per_img, total_tiles, st, InputXf{}, addend);
+    else if (wvec) launch_gemm_v<T, false, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, InputXf{}, addend);
+    else launch_gemm_v<T, false, false>(x, wv, y, HW, tiles_per_img, total_tiles, st, InputXf{}, addend);
     return check_launch(name);
 }
 
 static int gemm_entry(const char* name, const void* x, WView wv, void* y, int64_t N, int64_t HW, int dtype,
-                      void* stream) {
+                      void* stream, const void* addend = nullptr) {
     hipStream_t st = as_stream(stream);
     switch (dtype) {
-        case OFASR_F32: return launch_gemm<float>(name, x, wv, y, N, HW, st);
-        case OFASR_F16: return launch_gemm<f16_t>(name, x, wv, y, N, HW, st);
-        default: return launch_gemm<bf16_t>(name, x, wv, y, N, HW, st);
+        case OFASR_F32: return launch_gemm<float>(name, x, wv, y, N, HW, st, InputXf{}, addend);
+        case OFASR_F16: return launch_gemm<f16_t>(name, x, wv, y, N, HW, st, InputXf{}, addend);
+        default: return launch_gemm<bf16_t>(name, x, wv, y, N, HW, st, InputXf{}, addend);
     }
 }
 
@@ -794,7 +839,7 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
             int rc = check_launch(name);
             if (rc) return rc;
             const long long tot = (long long)wp.MR * wp.NS;
-            hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(256), 0, st, ws, dw, wp.MR,
+            hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(64 * WR_ZL), 0, st, ws, dw, wp.MR,
                                wp.NS, wp.nsplit, sr, ss);
             return check_launch(name);
         }
@@ -813,9 +858,20 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
     int rc = check_launch(name);
     if (rc) return rc;
     const long long tot = (long long)p.MR * p.NS;
-    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(256), 0, st, ws, dw, p.MR, p.NS,
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(64 * WR_ZL), 0, st, ws, dw, p.MR, p.NS,
                        p.nsplit, sr, ss);
     return check_launch(name);
+}
+
+int pwconv_dgrad_add(const void* dy, const float* w, int64_t ldw, void* dx, const void* addend, int64_t N, int64_t Cin,
+                     int64_t Cout, int64_t HW, int dtype, void* stream) {
+    const char* name = "pwconv_dgrad_add";
+    int rc = check_pw_args(name, dy, w, dx, ldw, N, Cin, Cout, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(addend != nullptr, OFASR_ERR_INVALID_ARG, "%s: null addend", name);
+    if (N * HW == 0) return OFASR_OK;
+    WView wv{w, 1, ldw, (int)Cin, (int)Cout};
+    return gemm_entry(name, dy, wv, dx, N, HW, dtype, stream, addend);
 }
 
 bool pwconv_xf_supported(const void* x, const void* y, int64_t HW, int dtype) {
