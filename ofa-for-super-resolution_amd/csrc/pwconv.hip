@@ -414,6 +414,13 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restri
 // any K, 64 output rows per grid.y pass.  K is walked in 64-channel chunks: each chunk stages its X
 // tile (HBM) and its [64 x 64] weight chunk (L2) and adds into accumulators that stay in registers.
 // wave w: output row block cb = w&1, pixel half hh = w>>1 (64 pixels, 2 per lane).
+// Measured timeline of one launch at 16x384->64x64x64 (wall_clock64 per block, all 512 blocks resident and in
+// lockstep): the X loads of a block take ~10 us to arrive (the tile pattern alone streams at 5.7 TB/s,
+// tools/probe/tile_read_probe.hip), vector-memory returns are in order so L2 weight loads issued after HBM X loads
+// wait behind them, the 6 LDS/MFMA rounds take 3.4 us and the stores 1.3 us -- and nothing overlaps because there is
+// a single generation of blocks.  Requesting every X chunk up front into registers (+ the whole weight slab in LDS)
+// made the isolated launch 10 % faster but the step slower (68 KB LDS, 2 blocks/CU); the next step is a persistent
+// block that streams tiles through a double buffer.
 template <typename T, bool ALIGNED, bool WVEC, bool XF = false>
 __global__ void __launch_bounds__(PW_THREADS) pw_fanin_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y,
                                                               int HW, int tiles_per_img, int kchunks,
@@ -968,3 +975,4 @@ OFASR_EXPORT int ofasr_pwconv_wgrad(const void* dy, const void* x, float* dw, in
         default: return launch_wgrad<bf16_t>(name, dy, x, dw, ldw, N, Cin, Cout, HW, ws, st);
     }
 }
+
