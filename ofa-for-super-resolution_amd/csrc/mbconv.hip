@@ -23,7 +23,8 @@ struct MbSizes {
     size_t ws_dw;
     size_t ws_pw;
     size_t ws_kt;
-    size_t scratch;       // region shared by whichever kernel is running
+    size_t scratch;       // main-stream region shared by whichever BN kernel is running
+    size_t side;          // side-stream region shared by whichever weight-gradient kernel is running
     size_t df_bytes;      // depthwise filter gradient (lives from dw wgrad to the kernel-transform backward)
     size_t total;
 };
@@ -42,14 +43,13 @@ static MbSizes mb_sizes(const ofasr_mbconv_desc* d) {
     size_t pw2 = ofasr_pwconv_wgrad_workspace(d->N, d->mid, d->Cout, HW);
     s.ws_pw = align_up(pw1 > pw2 ? pw1 : pw2, 256);
     s.ws_kt = align_up(ofasr_ktransform_bwd_workspace(d->ks, d->chain_len - 1, d->mid), 256);
-    // kernels run back to back on one stream, so the regions are reused: one slab sized for the largest user
-    size_t m = s.ws_bn;
-    if (s.ws_bn_bwd > m) m = s.ws_bn_bwd;
-    if (s.ws_dw > m) m = s.ws_dw;
-    if (s.ws_pw > m) m = s.ws_pw;
-    s.scratch = m;
+    // main stream: BN statistics / BN backward partials (kernels run back to back, so one slab for the largest user);
+    // side stream (weight-gradient kernels of the backward, ofasr_mbconv_bwd): its own slab + the depthwise filter
+    // gradient + the kernel-transform workspace, so the two streams never share scratch
+    s.scratch = s.ws_bn > s.ws_bn_bwd ? s.ws_bn : s.ws_bn_bwd;
+    s.side = s.ws_dw > s.ws_pw ? s.ws_dw : s.ws_pw;
     s.df_bytes = align_up((size_t)(d->mid * d->K * d->K) * sizeof(float), 256);
-    s.total = s.scratch + s.df_bytes + s.ws_kt + 256;
+    s.total = s.scratch + s.side + s.df_bytes + s.ws_kt + 256;
     return s;
 }
 
@@ -73,6 +73,32 @@ __global__ void bump_counters_kernel(int64_t* a, int64_t* b, int64_t* c) {
         if (b) *b += 1;
         if (c) *c += 1;
     }
+}
+
+// One non-blocking side stream + fork/join events per process (one process drives one GPU): the weight-gradient
+// kernels of a block's backward are independent of the input-gradient chain, so they run beside it and fill the
+// load / drain phases in which a lone bandwidth-bound kernel leaves HBM idle.  Created on first use; legal inside
+// hipGraph capture (fork/join through events).  OFASR_MBCONV_SIDE_STREAM=0 keeps everything on the caller's stream.
+struct SideStream {
+    bool ready = false, enabled = true;
+    hipStream_t s = nullptr;
+    hipEvent_t fork[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t join = nullptr;
+};
+static SideStream& side_stream() {
+    static SideStream ss;
+    if (!ss.ready) {
+        ss.ready = true;
+        const char* e = getenv("OFASR_MBCONV_SIDE_STREAM");
+        ss.enabled = !(e && e[0] == '0');
+        if (ss.enabled) {
+            bool ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess;
+            for (int i = 0; i < 3 && ok; ++i) ok = hipEventCreateWithFlags(&ss.fork[i], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
+            ss.enabled = ok;
+        }
+    }
+    return ss;
 }
 
 struct StatView {
@@ -269,56 +295,77 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     // BN3 (+shortcut, no activation): dy3; the shortcut's gradient is dout itself
     StatView s3 = stat_view(sb, 2, d->mid, d->Cout);
     rc = ofasr_bn_act_bwd(dout, y3, nullptr, t3, nullptr, s3.scale, s3.shift, s3.mean, s3.invstd, g->dgamma[2],
-                          g->dbeta[2], d->N, d->Cout, HW, 0, d->bn_training[2], d->dtype, workspace, workspace_bytes,
-                          stream);
+                          g->dbeta[2], d->N, d->Cout, HW, 0, d->bn_training[2], d->dtype, workspace, s.scratch, stream);
     if (rc) return rc;
-    // project 1x1
-    rc = ofasr_pwconv_dgrad(t3, d->w2, d->ldw2, tA, d->N, d->mid, d->Cout, HW, d->dtype, stream);
-    if (rc) return rc;
+    // From here the weight gradients go to the side stream: fork after the tensor they read is final, join at the end.
+    SideStream& ss = side_stream();
+    const bool par = ss.enabled;
+    void* sst = par ? (void*)ss.s : stream;   // stream of the weight-gradient kernels
+    char* side_ws = (char*)workspace + s.scratch;
+    float* dfp = (float*)(side_ws + s.side);
+    char* kt_ws = side_ws + s.side + s.df_bytes;
+    auto fork = [&](int i) -> int {
+        if (!par) return OFASR_OK;
+        hipError_t e1 = hipEventRecord(ss.fork[i], st);
+        if (e1 == hipSuccess) e1 = hipStreamWaitEvent(ss.s, ss.fork[i], 0);
+        OFASR_REQUIRE(e1 == hipSuccess, OFASR_ERR_LAUNCH, "%s: stream fork failed: %s", name, hipGetErrorString(e1));
+        return OFASR_OK;
+    };
     const bool fused = fuse_apply(d, s, act_buf);
-    if (fused) {
+    if (fused)
         OFASR_REQUIRE((reinterpret_cast<uintptr_t>(tmp_buf) & 15) == 0, OFASR_ERR_UNSUPPORTED,
                       "%s: tmp_buf must be 16-byte aligned (the forward pass did not materialise the activations)", name);
+    // project 1x1: weight gradient (side) beside input gradient + BN2 backward (main)
+    rc = fork(0);   // dy3 (t3) and the zeroed gradient buffers are final
+    if (rc) return rc;
+    if (fused)
         rc = pwconv_wgrad_xf(t3, y2, g->dw2, d->ldw2, d->N, d->mid, d->Cout, HW, d->dtype,
-                             xf_of(stat_buf, 1, d->mid, d->Cout), workspace, workspace_bytes, stream);
-    } else {
-        rc = ofasr_pwconv_wgrad(t3, a2, g->dw2, d->ldw2, d->N, d->mid, d->Cout, HW, d->dtype, workspace,
-                                workspace_bytes, stream);
-    }
+                             xf_of(stat_buf, 1, d->mid, d->Cout), side_ws, s.side, sst);
+    else
+        rc = ofasr_pwconv_wgrad(t3, a2, g->dw2, d->ldw2, d->N, d->mid, d->Cout, HW, d->dtype, side_ws, s.side, sst);
+    if (rc) return rc;
+    rc = ofasr_pwconv_dgrad(t3, d->w2, d->ldw2, tA, d->N, d->mid, d->Cout, HW, d->dtype, stream);
     if (rc) return rc;
     // BN2 + ReLU6 (in place: da2 -> dy2)
     StatView s2 = stat_view(sb, 1, d->mid, d->Cout);
     rc = ofasr_bn_act_bwd(tA, y2, nullptr, tA, nullptr, s2.scale, s2.shift, s2.mean, s2.invstd, g->dgamma[1],
-                          g->dbeta[1], d->N, d->mid, HW, 1, d->bn_training[1], d->dtype, workspace, workspace_bytes,
-                          stream);
+                          g->dbeta[1], d->N, d->mid, HW, 1, d->bn_training[1], d->dtype, workspace, s.scratch, stream);
     if (rc) return rc;
-    // depthwise: input gradient, filter gradient, and the filter's chain back to the max-size weight / matrices
-    rc = ofasr_dwconv_dgrad(tA, f, tB, d->N, d->mid, d->H, d->W, d->K, d->dtype, stream);
+    // depthwise: filter gradient and its chain back to the max-size weight / matrices (side) beside the input
+    // gradient + BN1 backward (main)
+    rc = fork(1);   // dy2 (tA) is final
     if (rc) return rc;
-    float* dfp = (float*)((char*)workspace + s.scratch);
     if (fused)
         rc = dwconv_wgrad_xf(tA, y1, dfp, d->N, d->mid, d->H, d->W, d->K, d->dtype, xf_of(stat_buf, 0, d->mid, d->Cout),
-                             workspace, s.scratch, stream);
+                             side_ws, s.side, sst);
     else
-        rc = ofasr_dwconv_wgrad(tA, a1, dfp, d->N, d->mid, d->H, d->W, d->K, d->dtype, workspace, s.scratch, stream);
+        rc = ofasr_dwconv_wgrad(tA, a1, dfp, d->N, d->mid, d->H, d->W, d->K, d->dtype, side_ws, s.side, sst);
     if (rc) return rc;
-    rc = ofasr_ktransform_bwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, dfp,
-                              g->dwdw_max, g->dmats, d->mid, (char*)workspace + s.scratch + s.df_bytes, s.ws_kt + 256,
-                              stream);
+    rc = ofasr_ktransform_bwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, dfp, g->dwdw_max, g->dmats,
+                              d->mid, kt_ws, s.ws_kt + 256, sst);
+    if (rc) return rc;
+    rc = ofasr_dwconv_dgrad(tA, f, tB, d->N, d->mid, d->H, d->W, d->K, d->dtype, stream);
     if (rc) return rc;
     // BN1 + ReLU6 (in place: da1 -> dy1)
     StatView s1 = stat_view(sb, 0, d->mid, d->Cout);
     rc = ofasr_bn_act_bwd(tB, y1, nullptr, tB, nullptr, s1.scale, s1.shift, s1.mean, s1.invstd, g->dgamma[0],
-                          g->dbeta[0], d->N, d->mid, HW, 1, d->bn_training[0], d->dtype, workspace, workspace_bytes,
-                          stream);
+                          g->dbeta[0], d->N, d->mid, HW, 1, d->bn_training[0], d->dtype, workspace, s.scratch, stream);
     if (rc) return rc;
-    // expand 1x1; x also feeds the identity shortcut, whose gradient (dout) is added in the dgrad epilogue
+    // expand 1x1: weight gradient (side) beside the input gradient (main); x also feeds the identity shortcut, whose
+    // gradient (dout) is added in the dgrad epilogue
+    rc = fork(2);   // dy1 (tB) is final
+    if (rc) return rc;
+    rc = ofasr_pwconv_wgrad(tB, x, g->dw1, d->ldw1, d->N, d->Cin, d->mid, HW, d->dtype, side_ws, s.side, sst);
+    if (rc) return rc;
     if (d->residual)
         rc = pwconv_dgrad_add(tB, d->w1, d->ldw1, dx, dout, d->N, d->Cin, d->mid, HW, d->dtype, stream);
     else
         rc = ofasr_pwconv_dgrad(tB, d->w1, d->ldw1, dx, d->N, d->Cin, d->mid, HW, d->dtype, stream);
     if (rc) return rc;
-    rc = ofasr_pwconv_wgrad(tB, x, g->dw1, d->ldw1, d->N, d->Cin, d->mid, HW, d->dtype, workspace, workspace_bytes,
-                            stream);
+    if (par) {   // join: everything this call enqueued is ordered before whatever the caller enqueues next
+        hipError_t e2 = hipEventRecord(ss.join, ss.s);
+        if (e2 == hipSuccess) e2 = hipStreamWaitEvent(st, ss.join, 0);
+        OFASR_REQUIRE(e2 == hipSuccess, OFASR_ERR_LAUNCH, "%s: stream join failed: %s", name, hipGetErrorString(e2));
+    }
     return rc;
 }

@@ -6,6 +6,7 @@ memory, the stream and the autograd graph; all arithmetic of these ops happens i
 csrc/*.hip.  There is no CPU / eager fallback: tensors must live on the GPU.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -475,6 +476,21 @@ class FusedMBConvFn(Function):
 
 
 # ------------------------------------------------------------------------------- dense KxK conv
+# static conv backward: weight gradient on a side stream beside the input gradient.  Off by default: measured 4 %
+# slower on the north-star step (tools/ab_side.py) -- the two MFMA kernels each want every CU's LDS -- while the same
+# fork/join inside the composite MB-block backward (bandwidth-bound kernels, csrc/mbconv.hip) is 6 % faster.
+SIDE_STREAM = os.environ.get("OFASR_CONV_SIDE_STREAM", "0") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index or 0
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 CONV_FORCE_HIP = False   # tests: every qualifying conv through the HIP kernel regardless of the measured policy
 HIP_CONV = True   # static ConvLayer convolutions (16-bit activations) through the implicit-GEMM HIP kernel
 
@@ -521,6 +537,20 @@ class Conv2dFn(Function):
                                                             [0, 0], 1, [ctx.needs_input_grad[0],
                                                                         ctx.needs_input_grad[1], False])
             return dx, (dw.float() if dw is not None else None), None
+        # weight gradient on a side stream beside the input gradient (both read dy; neither alone keeps HBM busy
+        # through its load / drain phases).  Buffers are allocated on the current stream; fork before, join after.
+        cur = torch.cuda.current_stream(x.device)
+        side = _side_stream(x.device) if (ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and SIDE_STREAM) else None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            wst2, wsp2, wsn2 = _ws(L.ofasr_conv2d_wgrad_workspace(N, Cin, Cout, H, W, K), x.device)
+            if side is not None:
+                side.wait_stream(cur)
+            with torch.cuda.stream(side if side is not None else cur):
+                with _timed("conv2d_wgrad_%dto%d_k%d" % (Cin, Cout, K), (x.numel() + dy.numel()) * x.element_size(),
+                            2 * N * H * W * Cin * Cout * K * K):
+                    _C.check(L.ofasr_conv2d_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Cout, H, W, K, _dt(x), wsp2, wsn2,
+                                                  _stream()), "conv2d_wgrad")
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wst, wsp, wsn = _ws(L.ofasr_conv2d_workspace(Cin, Cout, K, 1), x.device)
@@ -528,13 +558,8 @@ class Conv2dFn(Function):
                         2 * N * H * W * Cin * Cout * K * K):
                 _C.check(L.ofasr_conv2d_dgrad(_p(dy), _p(weight), _p(dx), N, Cin, Cout, H, W, K, _dt(x), wsp, wsn,
                                               _stream()), "conv2d_dgrad")
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
-            wst, wsp, wsn = _ws(L.ofasr_conv2d_wgrad_workspace(N, Cin, Cout, H, W, K), x.device)
-            with _timed("conv2d_wgrad_%dto%d_k%d" % (Cin, Cout, K), (x.numel() + dy.numel()) * x.element_size(),
-                        2 * N * H * W * Cin * Cout * K * K):
-                _C.check(L.ofasr_conv2d_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Cout, H, W, K, _dt(x), wsp, wsn, _stream()),
-                         "conv2d_wgrad")
+        if side is not None:
+            cur.wait_stream(side)
         return dx, dw, None
 
 
