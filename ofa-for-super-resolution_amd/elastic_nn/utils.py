@@ -24,12 +24,14 @@ def copy_bn(target_bn, src_bn):
     target_bn.running_var.data.copy_(src_bn.running_var.data[:n])
 
 
-def set_running_statistics(model, data_loader, input_key="2x_down_image", device=None):
+def set_running_statistics(model, data_loader, input_key="image", device=None, distributed=False):
     """Re-estimate BN running statistics of the ACTIVE sub-network (reference :16-64): every
     BatchNorm2d temporarily records the batch mean / variance it sees over `data_loader`, and
-    the averages (over batches) of the first `feature_dim` channels replace the running
-    statistics.  The reference feeds classification batches `(images, labels)`; the SR loaders
-    yield dicts, `input_key` picks the LR tensor."""
+    the batch-size-weighted averages (reference AverageMeter.update(val, x.size(0))) of the first
+    `feature_dim` channels replace the running statistics.  The reference reads `batch['image']`
+    (:55); `input_key` selects another tensor of the SR loaders' dicts.  `distributed` (Horovod
+    DistributedTensor in the reference) is accepted for signature parity; BN statistics stay rank-local
+    here like everywhere else in the data-parallel path."""
     from .modules.dynamic_op import DynamicBatchNorm2d
 
     stats = {}
@@ -43,10 +45,11 @@ def set_running_statistics(model, data_loader, input_key="2x_down_image", device
             mean = x.mean(dim=(0, 2, 3), keepdim=True)
             var = ((x - mean) ** 2).mean(dim=(0, 2, 3), keepdim=True)
             rec = stats[name]
-            m, v = mean.detach().flatten().float(), var.detach().flatten().float()
+            nb = x.size(0)
+            m, v = mean.detach().flatten().float() * nb, var.detach().flatten().float() * nb
             rec["mean_sum"] = m if rec["mean_sum"] is None else rec["mean_sum"] + m
             rec["var_sum"] = v if rec["var_sum"] is None else rec["var_sum"] + v
-            rec["n"] += 1
+            rec["n"] += nb
             c = mean.size(1)
             return F.batch_norm(x, mean.flatten(), var.flatten(), bn.weight[:c], bn.bias[:c], False, 0.0, bn.eps)
 
@@ -56,8 +59,10 @@ def set_running_statistics(model, data_loader, input_key="2x_down_image", device
         if isinstance(m, nn.BatchNorm2d):
             m.forward = hook(m, name)
 
-    flag = DynamicBatchNorm2d.SET_RUNNING_STATISTICS
+    from .. import ops
+    flag, fused = DynamicBatchNorm2d.SET_RUNNING_STATISTICS, ops.FUSED_BN
     DynamicBatchNorm2d.SET_RUNNING_STATISTICS = True
+    ops.FUSED_BN = False   # every BatchNorm2d must go through its (hooked) module forward, static ConvLayers included
     try:
         with torch.no_grad():
             for batch in data_loader:
@@ -65,6 +70,7 @@ def set_running_statistics(model, data_loader, input_key="2x_down_image", device
                 forward_model(x.to(device))
     finally:
         DynamicBatchNorm2d.SET_RUNNING_STATISTICS = flag
+        ops.FUSED_BN = fused
 
     for name, m in model.named_modules():
         rec = stats.get(name)

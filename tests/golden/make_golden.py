@@ -412,6 +412,30 @@ def gen_metric():
 
 
 # ------------------------------------------------------------------ a11 progressive-shrinking steps
+def gen_calibration():
+    """BN re-calibration of a sampled sub-network (reference ofa/elastic_nn/utils.py:16-64) on two batches of
+    different size (pins the batch-size weighting of the reference's AverageMeter)."""
+    from ofa.elastic_nn.networks import OFAMobileNetS4
+    from ofa.elastic_nn.utils import set_running_statistics
+    DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = 1
+    net = OFAMobileNetS4(ks_list=[3, 5, 7], expand_ratio_list=[3, 4, 6], depth_list=[2, 3, 4],
+                         pixelshuffle_depth_list=[1, 2])
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = fill_state_dict(shapes, "s4")
+    net.load_state_dict({k: T(v) for k, v in sd.items()})
+    net.eval()
+    net.set_active_subnet(ks=5, e=4, d=3, pixel_d=2)
+    b0 = det_uniform((2, 3, 12, 10), "cal/b0", 0.0, 1.0)
+    b1 = det_uniform((3, 3, 12, 10), "cal/b1", 0.0, 1.0)
+    loader = [{"image": T(b0)}, {"image": T(b1)}]
+    set_running_statistics(net, loader)
+    out = {"b0": b0, "b1": b1}
+    for k, v in net.state_dict().items():
+        if "running_mean" in k or "running_var" in k:
+            out[k] = A(v)
+    save("calibration", **out)
+
+
 def gen_trainer():
     """two optimizer steps of the progressive-shrinking hot loop (reference progressive_shrinking.py:152-203,
     transcribed around the REFERENCE net/optimizer because the original hard-codes .cuda()): per step,
@@ -474,6 +498,6 @@ def gen_trainer():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pwconv", "dwconv", "bn", "pixelshuffle", "mbblock", "s4", "metric", "trainer"]
+    which = sys.argv[1:] or ["pwconv", "dwconv", "bn", "pixelshuffle", "mbblock", "s4", "metric", "trainer", "calibration"]
     for w in which:
         globals()["gen_" + w]()

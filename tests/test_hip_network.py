@@ -219,3 +219,26 @@ def test_get_active_subnet_matches_supernet(mods):
         a, b = layer(x), sub(x)
     assert_close(H(b), H(a), 1e-5, 1e-6, "static sub-layer vs elastic layer")
     assert tuple(sub.depth_conv.conv.weight.shape) == (256, 1, 5, 5)
+
+
+def test_bn_recalibration_golden(mods, golden):
+    """set_running_statistics (reference ofa/elastic_nn/utils.py:16-64) on the sub-network (ks=5, e=4, d=3, pixel_d=2):
+    running statistics of every BatchNorm after two calibration batches of different size, against the reference's
+    own result (tests/golden/calibration.npz, make_golden.py gen_calibration)."""
+    g = golden("calibration.npz")
+    eutils = amd("elastic_nn.utils")
+    net = mods["nets"].OFAMobileNetS4(ks_list=[3, 5, 7], expand_ratio_list=[3, 4, 6], depth_list=[2, 3, 4],
+                                      pixelshuffle_depth_list=[1, 2])
+    _load(net, "s4")
+    net = net.to(DEV).eval()
+    net.set_active_subnet(ks=5, e=4, d=3, pixel_d=2)
+    before = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k}
+    loader = [{"image": G(g["b0"])}, {"image": G(g["b1"])}]
+    eutils.set_running_statistics(net, loader)
+    changed = 0
+    for k, v in net.state_dict().items():
+        if "running_mean" in k or "running_var" in k:
+            ref = g[k]
+            assert_close(H(v), ref, 2e-4, 2e-5 * max(1.0, float(np.abs(ref).max())), k)
+            changed += int(not torch.equal(v, before[k]))
+    assert changed > 40   # the active BNs were re-estimated, inactive ones (skipped depth) keep their values
