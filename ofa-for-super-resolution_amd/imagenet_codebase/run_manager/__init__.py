@@ -33,15 +33,16 @@ class SyntheticSRRunConfig(RunConfig):
 
 
 class Div2K_SetXXRunConfig(SyntheticSRRunConfig):
-    """reference :127-160.  The DIV2K/SetXX files (/SSD/div2k_setxx) and torchvision are absent in this
-    environment, so unless `save_path`/dataset directories exist the provider is the synthetic one of the
-    same interface (documented in DESIGN.md; the real provider is the 'next' row 8f-4)."""
+    """reference :127-160.  `data_provider` is the real Div2K_SetXXDataProvider (data_providers/div2k_setxx.py)
+    when `$OFASR_DIV2K_ROOT` (default /SSD/div2k_setxx, the reference's DEFAULT_PATH) holds `train/` and `val/`;
+    the DIV2K/SetXX files are absent in this environment, where it falls back to the synthetic provider of the same
+    interface."""
 
     def __init__(self, n_epochs=150, init_lr=0.05, lr_schedule_type="cosine", lr_schedule_param=None,
                  dataset="div2k_setxx", train_batch_size=256, test_batch_size=500, valid_size=None, opt_type="sgd",
                  opt_param=None, weight_decay=4e-5, label_smoothing=0.1, no_decay_keys=None, mixup_alpha=None,
                  model_init="he_fout", validation_frequency=1, print_frequency=10, n_worker=32,
-                 resize_scale=0.08, distort_color="tf", image_size=224, **kwargs):
+                 resize_scale=0.08, distort_color=None, image_size=32, **kwargs):
         super().__init__(n_epochs, init_lr, lr_schedule_type, lr_schedule_param, dataset, train_batch_size,
                          test_batch_size, valid_size, opt_type, opt_param, weight_decay, label_smoothing,
                          no_decay_keys, mixup_alpha, model_init, validation_frequency, print_frequency,
@@ -51,3 +52,20 @@ class Div2K_SetXXRunConfig(SyntheticSRRunConfig):
         self.resize_scale = resize_scale
         self.distort_color = distort_color
         self.dataset_root = os.environ.get("OFASR_DIV2K_ROOT", "/SSD/div2k_setxx")
+
+    @property
+    def data_provider(self):
+        if self.__dict__.get("_data_provider", None) is None:
+            root = self.dataset_root
+            if os.path.isdir(os.path.join(root, "train")) and os.path.isdir(os.path.join(root, "val")):
+                from ... import distributed as dd
+                from ..data_providers.div2k_setxx import Div2K_SetXXDataProvider
+                ws = dd.world_size()
+                self.__dict__["_data_provider"] = Div2K_SetXXDataProvider(
+                    save_path=root, train_batch_size=self.train_batch_size, test_batch_size=self.test_batch_size,
+                    valid_size=self.valid_size, n_worker=self.n_worker, resize_scale=self.resize_scale,
+                    distort_color=self.distort_color, image_size=self.image_size,
+                    num_replicas=ws if ws > 1 else None, rank=dd.rank() if ws > 1 else None)
+            else:
+                return super().data_provider
+        return self.__dict__["_data_provider"]

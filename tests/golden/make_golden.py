@@ -84,7 +84,7 @@ def A(t):
 
 
 def save(name, **arrs):
-    path = os.path.join(HERE, name)
+    path = os.path.join(HERE, name if name.endswith(".npz") else name + ".npz")
     np.savez_compressed(path, **arrs)
     print("wrote %-28s %8.1f KB" % (name, os.path.getsize(path) / 1024.0))
 
@@ -436,6 +436,28 @@ def gen_calibration():
     save("calibration", **out)
 
 
+def gen_div2k():
+    """deterministic pieces of the Div2K/SetXX data path, through the reference's own PIL code
+    (ofa/imagenet_codebase/data_providers/div2k_setxx.py:246-379): ModCrop(4), Scale(1/2), Scale(1/4) of one image and
+    the (duplicating) recursive file listing."""
+    import tempfile
+    from PIL import Image
+    from ofa.imagenet_codebase.data_providers.div2k_setxx import ModCrop, Scale, get_image_paths_recursive
+    from detfill import det_ints
+    hr = det_ints((37, 50, 3), "div2k/hr", 0, 256).astype(np.uint8)
+    img = Image.fromarray(hr, "RGB")
+    H = ModCrop(mod=4)(img)
+    L2 = Scale(scale_factor=1 / 2)(H)
+    L4 = Scale(scale_factor=1 / 4)(H)
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "sub", "deeper"))
+        for rel in ("a.png", "z.txt", os.path.join("sub", "b.png"), os.path.join("sub", "deeper", "c.jpg")):
+            open(os.path.join(d, rel), "wb").close()
+        listing = [os.path.relpath(q, d) for q in get_image_paths_recursive(d, [])]
+    save("div2k", hr=hr, H=np.asarray(H), L2=np.asarray(L2), L4=np.asarray(L4),
+         listing=np.array("|".join(listing)))
+
+
 def gen_trainer():
     """two optimizer steps of the progressive-shrinking hot loop (reference progressive_shrinking.py:152-203,
     transcribed around the REFERENCE net/optimizer because the original hard-codes .cuda()): per step,
@@ -498,6 +520,6 @@ def gen_trainer():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pwconv", "dwconv", "bn", "pixelshuffle", "mbblock", "s4", "metric", "trainer", "calibration"]
+    which = sys.argv[1:] or ["pwconv", "dwconv", "bn", "pixelshuffle", "mbblock", "s4", "metric", "trainer", "calibration", "div2k"]
     for w in which:
         globals()["gen_" + w]()
