@@ -473,6 +473,69 @@ OFASR_EXPORT int ofasr_bn_finalize(const void* workspace, int64_t n_partials, in
 }
 
 namespace ofasr {
+// one wave per channel: lane l sums partials l, l+64, ... in fp64, then a fixed-order butterfly
+__global__ void __launch_bounds__(64) bn_finalize_cp_kernel(const float2* __restrict__ partial, int P, int C, double M,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var, double momentum, double eps,
+                                                            int training, float* __restrict__ mean_out,
+                                                            float* __restrict__ invstd_out, float* __restrict__ scale,
+                                                            float* __restrict__ shift, int64_t* k0, int64_t* k1,
+                                                            int64_t* k2) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (c == 0 && lane == 0) {
+        if (k0) *k0 += 1;
+        if (k1) *k1 += 1;
+        if (k2) *k2 += 1;
+    }
+    double mean, var;
+    if (training) {
+        double s = 0.0, ss = 0.0;
+        for (int p = lane; p < P; p += 64) {
+            const float2 v = partial[(long long)c * P + p];
+            s += (double)v.x;
+            ss += (double)v.y;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            ss += __shfl_xor(ss, o, 64);
+        }
+        mean = s / M;
+        var = ss / M - mean * mean;
+        if (var < 0.0) var = 0.0;
+    } else {
+        mean = (double)running_mean[c];
+        var = (double)running_var[c];
+    }
+    if (lane != 0) return;
+    if (training && running_mean) {
+        const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+    const double invstd = 1.0 / sqrt(var + eps);
+    const double g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = (float)invstd;
+    scale[c] = (float)(g * invstd);
+    shift[c] = (float)(b - mean * g * invstd);
+}
+
+int bn_finalize_cp(const float2* partial, int64_t P, int64_t C, double count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, double momentum, double eps, int training, float* mean,
+                   float* invstd, float* scale, float* shift, int64_t* k0, int64_t* k1, int64_t* k2, void* stream) {
+    const char* name = "bn_finalize_cp";
+    OFASR_REQUIRE(C > 0 && mean && invstd && scale && shift, OFASR_ERR_INVALID_ARG, "%s: null output or C<=0", name);
+    OFASR_REQUIRE(training ? (partial != nullptr && P > 0 && count > 0) : (running_mean && running_var),
+                  OFASR_ERR_INVALID_ARG, "%s: missing statistics source", name);
+    hipLaunchKernelGGL(bn_finalize_cp_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(stream), partial, (int)P, (int)C,
+                       count, gamma, beta, running_mean, running_var, momentum, eps, training, mean, invstd, scale, shift,
+                       k0, k1, k2);
+    return check_launch(name);
+}
+
 int bn_finalize_bump(const void* workspace, int64_t n_partials, int64_t C, double count, const float* gamma,
                      const float* beta, float* running_mean, float* running_var, double momentum, double eps,
                      int training, float* mean, float* invstd, float* scale, float* shift, int64_t* k0, int64_t* k1,

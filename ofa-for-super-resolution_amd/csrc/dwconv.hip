@@ -299,10 +299,11 @@ struct VecGeom {
 };
 
 // wave = (plane, slab); group g of the wave owns rows [slab*gpw*R + g*R, +R) of that plane
-template <typename T, int K, bool FLIP, bool XF = false>
+template <typename T, int K, bool FLIP, bool XF = false, bool STAT = false>
 __global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restrict__ x, const float* __restrict__ f,
                                                                T* __restrict__ y, int C, int H, int W, VecGeom vg,
-                                                               long long nwaves, InputXf xf = InputXf{}) {
+                                                               long long nwaves, InputXf xf = InputXf{},
+                                                               StatOut so = StatOut{nullptr, 0}) {
     constexpr int PAD = K / 2;
     constexpr int PXL = VecPx<T, K>::N;
     typedef PxIO<T, PXL> IO;
@@ -340,6 +341,7 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restri
 #pragma unroll
         for (int p = 0; p < PXL; ++p) acc[i][p] = 0.f;
 
+    float st_s = 0.f, st_q = 0.f;
     const int hstart = h0 - PAD;
     const int niter_max = vg.R + 2 * PAD;            // wave-uniform trip count (shuffles need every lane)
     const int niter = (h1 - h0) + 2 * PAD;
@@ -379,10 +381,26 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restri
                 }
             }
             const int hout = hin - PAD;
-            if (t < niter && hout >= h0 && hout < h1) yp[(long long)hout * Wq] = IO::pack(acc[(u + 1) % K]);
+            if (t < niter && hout >= h0 && hout < h1) {
+                const raw_t o = IO::pack(acc[(u + 1) % K]);
+                yp[(long long)hout * Wq] = o;
+                if constexpr (STAT) {   // statistics of the values as stored (rounded to T)
+                    float r[PXL];
+                    IO::unpack(o, r);
+#pragma unroll
+                    for (int p = 0; p < PXL; ++p) {
+                        st_s += r[p];
+                        st_q = fmaf(r[p], r[p], st_q);
+                    }
+                }
+            }
 #pragma unroll
             for (int p = 0; p < PXL; ++p) acc[(u + 1) % K][p] = 0.f;
         }
+    }
+    if constexpr (STAT) {   // one (sum, sum of squares) per wave = per (image, slab) of channel c
+        const float s = wave_sum(st_s), q = wave_sum(st_q);
+        if (lane == 0) so.partial[(long long)c * so.P + (plane / C) * vg.nslabs + slab] = make_float2(s, q);
     }
 }
 
@@ -521,17 +539,21 @@ static int wgrad_parts(int64_t N, int64_t C) {
     return (int)want;
 }
 
-template <typename T, bool FLIP, bool XF = false>
+template <typename T, bool FLIP, bool XF = false, bool STAT = false>
 static int launch_conv(const char* name, const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H,
-                       int64_t W, int K, hipStream_t st, InputXf xf = InputXf{}) {
+                       int64_t W, int K, hipStream_t st, InputXf xf = InputXf{}, StatOut so = StatOut{nullptr, 0}) {
     {
         VecGeom vg;
 #define OFASR_DWV(KK)                                                                                               \
     if (vec_geom(H, W, (int)sizeof(T), VecPx<T, KK>::N, x, y, vg)) {                                               \
         const long long nwaves = (long long)N * C * vg.nslabs;                                                     \
-        hipLaunchKernelGGL((dw_vec_kernel<T, KK, FLIP, XF>), dim3((unsigned)cdiv(nwaves, DW_WAVES)),               \
+        if (STAT && so.P != (int)(N * vg.nslabs)) {                                                                \
+            set_error("%s: statistics slab count %d != %lld", name, so.P, (long long)(N * vg.nslabs));             \
+            return OFASR_ERR_INVALID_ARG;                                                                          \
+        }                                                                                                          \
+        hipLaunchKernelGGL((dw_vec_kernel<T, KK, FLIP, XF, STAT>), dim3((unsigned)cdiv(nwaves, DW_WAVES)),         \
                            dim3(64 * DW_WAVES), 0, st, (const T*)x, f, (T*)y, (int)C, (int)H, (int)W, vg, nwaves,  \
-                           xf);                                                                                    \
+                           xf, so);                                                                                \
         return check_launch(name);                                                                                 \
     }
         switch (K) {
@@ -650,8 +672,16 @@ bool dwconv_xf_supported(const void* x, const void* y, int64_t H, int64_t W, int
     return vec_geom(H, W, 2, pxl, x, y, vg) && vec_geom(H, W, 2, 4, x, y, vg);
 }
 
+int dwconv_stat_units(int64_t N, int64_t H, int64_t W, int K, int dtype) {
+    VecGeom vg;
+    const int pxl = (K <= 3 && dtype != OFASR_F32) ? 8 : 4;
+    static const char dummy[16] __attribute__((aligned(16))) = {0};
+    if (!vec_geom(H, W, 2, pxl, dummy, dummy, vg)) return 0;
+    return (int)(N * vg.nslabs);
+}
+
 int dwconv_fwd_xf(const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H, int64_t W, int K, int dtype,
-                  InputXf xf, void* stream) {
+                  InputXf xf, void* stream, StatOut so) {
     const char* name = "dwconv_fwd_xf";
     int rc = check_conv_args(name, x, f, y, N, C, H, W, K, dtype);
     if (rc) return rc;
@@ -659,6 +689,10 @@ int dwconv_fwd_xf(const void* x, const float* f, void* y, int64_t N, int64_t C, 
     OFASR_REQUIRE(dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_UNSUPPORTED, "%s: 16-bit only", name);
     if (N * C * H * W == 0) return OFASR_OK;
     hipStream_t st = as_stream(stream);
+    if (so.partial) {
+        if (dtype == OFASR_F16) return launch_conv<f16_t, false, true, true>(name, x, f, y, N, C, H, W, K, st, xf, so);
+        return launch_conv<bf16_t, false, true, true>(name, x, f, y, N, C, H, W, K, st, xf, so);
+    }
     if (dtype == OFASR_F16) return launch_conv<f16_t, false, true>(name, x, f, y, N, C, H, W, K, st, xf);
     return launch_conv<bf16_t, false, true>(name, x, f, y, N, C, H, W, K, st, xf);
 }

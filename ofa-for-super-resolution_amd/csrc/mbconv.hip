@@ -47,6 +47,15 @@ static MbSizes mb_sizes(const ofasr_mbconv_desc* d) {
     // side stream (weight-gradient kernels of the backward, ofasr_mbconv_bwd): its own slab + the depthwise filter
     // gradient + the kernel-transform workspace, so the two streams never share scratch
     s.scratch = s.ws_bn > s.ws_bn_bwd ? s.ws_bn : s.ws_bn_bwd;
+    {   // statistics partials written by the conv kernels themselves (fused forward): [C][units] float2
+        const size_t u1 = (size_t)pwconv_stat_units(d->N, d->Cin, HW) * (size_t)d->mid;
+        const size_t u2 = (size_t)dwconv_stat_units(d->N, d->H, d->W, d->K, d->dtype) * (size_t)d->mid;
+        const size_t u3 = (size_t)pwconv_stat_units(d->N, d->mid, HW) * (size_t)d->Cout;
+        size_t u = u1 > u2 ? u1 : u2;
+        u = u > u3 ? u : u3;
+        const size_t ws_stat = align_up(u * sizeof(float2), 256);
+        if (ws_stat > s.scratch) s.scratch = ws_stat;
+    }
     s.side = s.ws_dw > s.ws_pw ? s.ws_dw : s.ws_pw;
     s.df_bytes = align_up((size_t)(d->mid * d->K * d->K) * sizeof(float), 256);
     s.total = s.scratch + s.side + s.df_bytes + s.ws_kt + 256;
@@ -121,25 +130,6 @@ static int bn_forward(const ofasr_mbconv_desc* d, int which, const void* x, cons
                         d->dtype, ws, ws_bytes, stream);
 }
 
-// statistics of one of the block's BNs without the apply pass: mean | invstd | scale | shift (+ running stats);
-// the consumer kernel applies scale/shift + ReLU6 as it reads the tensor (InputXf)
-static int bn_statistics(const ofasr_mbconv_desc* d, int which, const void* x, int64_t C, float* stat_buf, void* ws,
-                         size_t ws_bytes, void* stream, bool bump = false) {
-    const int64_t HW = d->H * d->W;
-    StatView sv = stat_view(stat_buf, which, d->mid, d->Cout);
-    const int training = d->bn_training[which];
-    if (training) {
-        int rc = ofasr_bn_stats(x, d->N, C, HW, d->dtype, ws, ws_bytes, stream);
-        if (rc) return rc;
-    }
-    int64_t* k[3] = {nullptr, nullptr, nullptr};
-    if (bump)
-        for (int i = 0; i < 3; ++i) k[i] = d->bn_training[i] ? d->num_batches_tracked[i] : nullptr;
-    return bn_finalize_bump(ws, ofasr_bn_partials(d->N, C), C, (double)d->N * (double)HW, d->gamma[which],
-                            d->beta[which], d->running_mean[which], d->running_var[which], d->bn_momentum[which],
-                            d->bn_eps[which], training, sv.mean, sv.invstd, sv.scale, sv.shift, k[0], k[1], k[2], stream);
-}
-
 static InputXf xf_of(const float* stat_buf, int which, int64_t mid, int64_t cout) {
     StatView sv = stat_view(const_cast<float*>(stat_buf), which, mid, cout);
     return InputXf{sv.scale, sv.shift, sv.mean};
@@ -201,23 +191,68 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
         if (rc) return rc;
     }
     // expand 1x1 -> BN + ReLU6
-    rc = ofasr_pwconv_fwd(x, d->w1, d->ldw1, y1, d->N, d->Cin, d->mid, HW, d->dtype, stream);
+    // statistics in the pointwise kernels' epilogue cost almost what the statistics pass they replace costs (a
+    // 5-round cross-lane reduce at the tail of a kernel whose blocks all run in phase): +0.8 % on the step, kept behind
+    // a switch (OFASR_PW_EPILOGUE_STATS=0 goes back to the pass); the depthwise kernel's statistics are free (one wave
+    // owns a whole plane).
+    static const bool pw_stat = [] { const char* e = getenv("OFASR_PW_EPILOGUE_STATS"); return !(e && e[0] == '0'); }();
+    if (fused && pw_stat && d->bn_training[0])
+        rc = pwconv_fwd_stat(x, d->w1, d->ldw1, y1, d->N, d->Cin, d->mid, HW, d->dtype,
+                             StatOut{(float2*)workspace, pwconv_stat_units(d->N, d->Cin, HW)}, stream);
+    else
+        rc = ofasr_pwconv_fwd(x, d->w1, d->ldw1, y1, d->N, d->Cin, d->mid, HW, d->dtype, stream);
     if (rc) return rc;
     if (fused) {
-        rc = bn_statistics(d, 0, y1, d->mid, stat_buf, workspace, workspace_bytes, stream, true);
+        // the conv kernels leave their output's per-channel (sum, sum of squares) partials in the epilogue; a one-wave-
+        // per-channel finalize turns them into scale/shift (+ running statistics, + the three counters): no pass over
+        // the tensors for statistics, no pass for BN1/BN2 + ReLU6 (applied by the consumer's loads)
+        const double count = (double)d->N * (double)HW;
+        float2* part = (float2*)workspace;
+        auto finalize = [&](int which, int64_t C, int P, bool bump) -> int {
+            StatView sv = stat_view(stat_buf, which, d->mid, d->Cout);
+            int64_t* k[3] = {nullptr, nullptr, nullptr};
+            if (bump)
+                for (int i = 0; i < 3; ++i) k[i] = d->bn_training[i] ? d->num_batches_tracked[i] : nullptr;
+            return bn_finalize_cp(part, P, C, count, d->gamma[which], d->beta[which], d->running_mean[which],
+                                  d->running_var[which], d->bn_momentum[which], d->bn_eps[which], d->bn_training[which],
+                                  sv.mean, sv.invstd, sv.scale, sv.shift, k[0], k[1], k[2], stream);
+        };
+        const int P1 = pwconv_stat_units(d->N, d->Cin, HW);
+        const int P2 = dwconv_stat_units(d->N, d->H, d->W, d->K, d->dtype);
+        const int P3 = pwconv_stat_units(d->N, d->mid, HW);
+        // statistics by a pass over the tensor (the pointwise default): fp64 partial slabs + the classic finalize
+        auto pass_stats = [&](int which, const void* t, int64_t C, bool bump) -> int {
+            StatView sv = stat_view(stat_buf, which, d->mid, d->Cout);
+            if (d->bn_training[which]) {
+                int r2 = ofasr_bn_stats(t, d->N, C, HW, d->dtype, workspace, s.scratch, stream);
+                if (r2) return r2;
+            }
+            int64_t* k[3] = {nullptr, nullptr, nullptr};
+            if (bump)
+                for (int i = 0; i < 3; ++i) k[i] = d->bn_training[i] ? d->num_batches_tracked[i] : nullptr;
+            return bn_finalize_bump(workspace, ofasr_bn_partials(d->N, C), C, count, d->gamma[which], d->beta[which],
+                                    d->running_mean[which], d->running_var[which], d->bn_momentum[which],
+                                    d->bn_eps[which], d->bn_training[which], sv.mean, sv.invstd, sv.scale, sv.shift,
+                                    k[0], k[1], k[2], stream);
+        };
+        rc = pw_stat ? finalize(0, d->mid, P1, true) : pass_stats(0, y1, d->mid, true);
         if (rc) return rc;
         rc = ofasr_ktransform_fwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, f, d->mid, stream);
         if (rc) return rc;
         rc = dwconv_fwd_xf(y1, f, y2, d->N, d->mid, d->H, d->W, d->K, d->dtype, xf_of(stat_buf, 0, d->mid, d->Cout),
-                           stream);
+                           stream, StatOut{d->bn_training[1] ? part : nullptr, P2});
         if (rc) return rc;
-        rc = bn_statistics(d, 1, y2, d->mid, stat_buf, workspace, workspace_bytes, stream);
+        rc = finalize(1, d->mid, P2, false);
         if (rc) return rc;
         rc = pwconv_fwd_xf(y2, d->w2, d->ldw2, y3, d->N, d->mid, d->Cout, HW, d->dtype,
-                           xf_of(stat_buf, 1, d->mid, d->Cout), stream);
+                           xf_of(stat_buf, 1, d->mid, d->Cout), stream,
+                           StatOut{(pw_stat && d->bn_training[2]) ? part : nullptr, P3});
         if (rc) return rc;
-        return bn_forward(d, 2, y3, d->residual ? x : nullptr, out, d->Cout, 0, stat_buf, workspace, workspace_bytes,
-                          stream);
+        rc = pw_stat ? finalize(2, d->Cout, P3, false) : pass_stats(2, y3, d->Cout, false);
+        if (rc) return rc;
+        StatView s3 = stat_view(stat_buf, 2, d->mid, d->Cout);
+        return ofasr_bn_act_fwd(y3, d->residual ? x : nullptr, out, s3.scale, s3.shift, s3.mean, d->N, d->Cout, HW, 0,
+                                d->dtype, stream);
     }
     rc = bn_forward(d, 0, y1, nullptr, a1, d->mid, 1, stat_buf, workspace, workspace_bytes, stream);
     if (rc) return rc;

@@ -94,11 +94,26 @@ struct InputXf {
     const float* mean;
 };
 
+// Optional BatchNorm statistics of the tensor a conv kernel writes: every producer unit p (a pixel tile, a plane slab)
+// leaves its per-channel (sum, sum of squares) at partial[c * P + p] -- fp32 over <= a few thousand values -- and
+// bn_finalize_cp folds the P partials of a channel in fp64 in a fixed order.  partial == nullptr: no statistics.
+struct StatOut {
+    float2* partial;
+    int P;
+};
+// number of producer units per channel of the kernels that take a StatOut
+int dwconv_stat_units(int64_t N, int64_t H, int64_t W, int K, int dtype);
+int pwconv_stat_units(int64_t N, int64_t Cin, int64_t HW);
+// mean | invstd | scale | shift (+ running statistics, + up to three counters) from [C][P] partials
+int bn_finalize_cp(const float2* partial, int64_t P, int64_t C, double count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, double momentum, double eps, int training, float* mean,
+                   float* invstd, float* scale, float* shift, int64_t* k0, int64_t* k1, int64_t* k2, void* stream);
+
 // internal (not exported) variants used by mbconv.hip; they return OFASR_ERR_UNSUPPORTED (and launch nothing) when
 // the vector / aligned 16-bit kernels that implement the fused read do not apply to the shape.
 bool dwconv_xf_supported(const void* x, const void* y, int64_t H, int64_t W, int K, int dtype);
 int dwconv_fwd_xf(const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H, int64_t W, int K, int dtype,
-                  InputXf xf, void* stream);
+                  InputXf xf, void* stream, StatOut so = StatOut{nullptr, 0});
 int dwconv_wgrad_xf(const void* dy, const void* x, float* df, int64_t N, int64_t C, int64_t H, int64_t W, int K,
                     int dtype, InputXf xf, void* workspace, size_t workspace_bytes, void* stream);
 // ofasr_bn_finalize that also bumps up to three num_batches_tracked counters (thread 0)
@@ -111,7 +126,10 @@ int pwconv_dgrad_add(const void* dy, const float* w, int64_t ldw, void* dx, cons
                      int64_t Cout, int64_t HW, int dtype, void* stream);
 bool pwconv_xf_supported(const void* x, const void* y, int64_t HW, int dtype);
 int pwconv_fwd_xf(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t HW,
-                  int dtype, InputXf xf, void* stream);
+                  int dtype, InputXf xf, void* stream, StatOut so = StatOut{nullptr, 0});
+// plain forward (no input transform) that leaves the output's statistics partials
+int pwconv_fwd_stat(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin, int64_t Cout,
+                    int64_t HW, int dtype, StatOut so, void* stream);
 int pwconv_wgrad_xf(const void* dy, const void* x, float* dw, int64_t ldw, int64_t N, int64_t Cin, int64_t Cout,
                     int64_t HW, int dtype, InputXf xf, void* workspace, size_t workspace_bytes, void* stream);
 

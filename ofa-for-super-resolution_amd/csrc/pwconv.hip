@@ -340,6 +340,69 @@ __device__ __forceinline__ void add_px(const T* __restrict__ src, int px, int HW
     }
 }
 
+// BatchNorm statistics epilogue: v[reg] is this lane's partial sum for accumulator register reg (row acc_row(reg, h)).
+// A reduce-scatter over the 32 lanes of the half-wave (16 shuffles instead of 16 x 5) leaves in v[0] the total of
+// register rho(c) = 8*b4 + 4*b3 + 2*b2 + b1 (bits of the lane's column c), identical in the two lanes of a b0 pair.
+__device__ __forceinline__ void half_wave_row_sums(float (&v)[16], float (&w)[16], int c) {
+    // both quantities level by level, so the 2 x (8 + 4 + 2 + 1 + 1) cross-lane moves form 5 dependent rounds, not 10
+    const bool b4 = c & 16, b3 = c & 8, b2 = c & 4, b1 = c & 2;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float kv = b4 ? v[r + 8] : v[r], sv = b4 ? v[r] : v[r + 8];
+        const float kw = b4 ? w[r + 8] : w[r], sw = b4 ? w[r] : w[r + 8];
+        v[r] = kv + __shfl_xor(sv, 16, 64);
+        w[r] = kw + __shfl_xor(sw, 16, 64);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float kv = b3 ? v[r + 4] : v[r], sv = b3 ? v[r] : v[r + 4];
+        const float kw = b3 ? w[r + 4] : w[r], sw = b3 ? w[r] : w[r + 4];
+        v[r] = kv + __shfl_xor(sv, 8, 64);
+        w[r] = kw + __shfl_xor(sw, 8, 64);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const float kv = b2 ? v[r + 2] : v[r], sv = b2 ? v[r] : v[r + 2];
+        const float kw = b2 ? w[r + 2] : w[r], sw = b2 ? w[r] : w[r + 2];
+        v[r] = kv + __shfl_xor(sv, 4, 64);
+        w[r] = kw + __shfl_xor(sw, 4, 64);
+    }
+    {
+        const float kv = b1 ? v[1] : v[0], sv = b1 ? v[0] : v[1];
+        const float kw = b1 ? w[1] : w[0], sw = b1 ? w[0] : w[1];
+        v[0] = kv + __shfl_xor(sv, 2, 64);
+        w[0] = kw + __shfl_xor(sw, 2, 64);
+    }
+    v[0] += __shfl_xor(v[0], 1, 64);
+    w[0] += __shfl_xor(w[0], 1, 64);
+}
+__device__ __forceinline__ int half_wave_row_reg(int c) { return ((c >> 4) & 1) * 8 + ((c >> 3) & 1) * 4 + ((c >> 2) & 1) * 2 + ((c >> 1) & 1); }
+
+// statistics of NSUB accumulator sub-tiles (PX = NSUB adjacent pixels per lane starting at px) of one 32-row block
+template <typename T, int NSUB>
+__device__ __forceinline__ void stat_epilogue(const f32x16* acc, int px, int HW, int c, int h, int row_base, int mloc,
+                                              long long chan_base, StatOut so, int unit) {
+    float s[16], q[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        float ss = 0.f, qq = 0.f;
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t) {
+            float v = acc[t][reg];
+            if constexpr (Elem<T>::is16) v = to_float(from_float<T>(v));   // the values as stored
+            if (px + t < HW) {
+                ss += v;
+                qq = fmaf(v, v, qq);
+            }
+        }
+        s[reg] = ss;
+        q[reg] = qq;
+    }
+    half_wave_row_sums(s, q, c);
+    const int r = row_base + acc_row(half_wave_row_reg(c), h);
+    if ((c & 1) == 0 && r < mloc) so.partial[(chan_base + r) * so.P + unit] = make_float2(s[0], q[0]);
+}
+
 // ------------------------------------------------------------------------------------ fan-out
 // K <= 64.  One block = one 128-pixel tile x one 128-row slab of outputs (grid.y); wave w owns output
 // row block w of the slab: A (weights) from the swizzled LDS operand tile, B (pixels) by transposing
@@ -349,7 +412,8 @@ constexpr int FO_ROWS = 128;
 template <typename T, bool ALIGNED, bool WVEC, bool XF = false>
 __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y,
                                                                int HW, int tiles_per_img, InputXf xf = InputXf{},
-                                                               const T* __restrict__ addend = nullptr) {
+                                                               const T* __restrict__ addend = nullptr,
+                                                               StatOut so = StatOut{nullptr, 0}) {
     __shared__ __attribute__((aligned(16))) char Ws[FO_ROWS * Elem<T>::wrow];
     __shared__ __attribute__((aligned(16))) char Xs[64 * Elem<T>::xrow];
     const int m_base = blockIdx.y * FO_ROWS;
@@ -408,6 +472,7 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restri
             store_px<T, 4, ALIGNED>(yn + (long long)r * HW, p0 + 4 * c, HW, v);
         }
     }
+    if (so.partial) stat_epilogue<T, 4>(acc, p0 + 4 * c, HW, c, h, 32 * cb, mloc, m_base, so, tile);
 }
 
 // ------------------------------------------------------------------------------------- fan-in
@@ -425,7 +490,8 @@ template <typename T, bool ALIGNED, bool WVEC, bool XF = false>
 __global__ void __launch_bounds__(PW_THREADS) pw_fanin_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y,
                                                               int HW, int tiles_per_img, int kchunks,
                                                               InputXf xf = InputXf{},
-                                                              const T* __restrict__ addend = nullptr) {
+                                                              const T* __restrict__ addend = nullptr,
+                                                              StatOut so = StatOut{nullptr, 0}) {
     __shared__ __attribute__((aligned(16))) char Ws[64 * Elem<T>::wrow];
     __shared__ __attribute__((aligned(16))) char Xs[64 * Elem<T>::xrow];
     const int m_base = blockIdx.y * 64;
@@ -482,6 +548,7 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_kernel(const T* __restric
             store_px<T, 2, ALIGNED>(yn + (long long)r * HW, p0 + 64 * hh + 2 * c, HW, v);
         }
     }
+    if (so.partial) stat_epilogue<T, 2>(acc, p0 + 64 * hh + 2 * c, HW, c, h, 32 * cb, mloc, m_base, so, 2 * tile + hh);
 }
 
 // -------------------------------------------------------------------------------------- wgrad
@@ -757,21 +824,22 @@ static bool aligned_for(const void* a, const void* b, int64_t HW, bool is16) {
 
 template <typename T, bool AL, bool WV, bool XF = false>
 static void launch_gemm_v(const void* x, WView wv, void* y, int64_t HW, int tiles_per_img, int total_tiles,
-                          hipStream_t st, InputXf xf = InputXf{}, const void* addend = nullptr) {
+                          hipStream_t st, InputXf xf = InputXf{}, const void* addend = nullptr,
+                          StatOut so = StatOut{nullptr, 0}) {
     if (wv.K <= 64) {
         dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, FO_ROWS));
         hipLaunchKernelGGL((pw_fanout_kernel<T, AL, WV, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
-                           (int)HW, tiles_per_img, xf, (const T*)addend);
+                           (int)HW, tiles_per_img, xf, (const T*)addend, so);
     } else {
         dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, 64));
         hipLaunchKernelGGL((pw_fanin_kernel<T, AL, WV, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
-                           (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf, (const T*)addend);
+                           (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf, (const T*)addend, so);
     }
 }
 
 template <typename T, bool XF = false>
 static int launch_gemm(const char* name, const void* x, WView wv, void* y, int64_t N, int64_t HW, hipStream_t st,
-                       InputXf xf = InputXf{}, const void* addend = nullptr) {
+                       InputXf xf = InputXf{}, const void* addend = nullptr, StatOut so = StatOut{nullptr, 0}) {
     constexpr bool is16 = Elem<T>::is16;
     const bool al = aligned_for(x, y, HW, is16);
     const long long ld = wv.sk == 1 ? wv.sm : wv.sk;
@@ -780,27 +848,30 @@ static int launch_gemm(const char* name, const void* x, WView wv, void* y, int64
     const int64_t total64 = N * tiles_per_img;
     OFASR_REQUIRE(total64 <= INT32_MAX, OFASR_ERR_UNSUPPORTED, "%s: too many pixel tiles", name);
     const int total_tiles = (int)total64;
+    if (so.partial)
+        OFASR_REQUIRE(so.P == (wv.K <= 64 ? total_tiles : 2 * total_tiles), OFASR_ERR_INVALID_ARG,
+                      "%s: statistics unit count %d does not match the launch", name, so.P);
     if constexpr (XF) {
         OFASR_REQUIRE(al && is16, OFASR_ERR_UNSUPPORTED, "%s: fused input transform needs aligned 16-bit tensors", name);
-        if (wvec) launch_gemm_v<T, true, true, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, xf);
-        else launch_gemm_v<T, true, false, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, xf);
+        if (wvec) launch_gemm_v<T, true, true, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, xf, nullptr, so);
+        else launch_gemm_v<T, true, false, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, xf, nullptr, so);
         return check_launch(name);
     }
     const bool al2 = al && (addend == nullptr || (reinterpret_cast<uintptr_t>(addend) & 15) == 0);
-    if (al2 && wvec) launch_gemm_v<T, true, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, InputXf{}, addend);
-    else if (al2) launch_gemm_v<T, true, false>(x, wv, y, HW, tiles_per_img, total_tiles, st, InputXf{}, addend);
-    else if (wvec) launch_gemm_v<T, false, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, InputXf{}, addend);
-    else launch_gemm_v<T, false, false>(x, wv, y, HW, tiles_per_img, total_tiles, st, InputXf{}, addend);
+    if (al2 && wvec) launch_gemm_v<T, true, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, InputXf{}, addend, so);
+    else if (al2) launch_gemm_v<T, true, false>(x, wv, y, HW, tiles_per_img, total_tiles, st, InputXf{}, addend, so);
+    else if (wvec) launch_gemm_v<T, false, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, InputXf{}, addend, so);
+    else launch_gemm_v<T, false, false>(x, wv, y, HW, tiles_per_img, total_tiles, st, InputXf{}, addend, so);
     return check_launch(name);
 }
 
 static int gemm_entry(const char* name, const void* x, WView wv, void* y, int64_t N, int64_t HW, int dtype,
-                      void* stream, const void* addend = nullptr) {
+                      void* stream, const void* addend = nullptr, StatOut so = StatOut{nullptr, 0}) {
     hipStream_t st = as_stream(stream);
     switch (dtype) {
-        case OFASR_F32: return launch_gemm<float>(name, x, wv, y, N, HW, st, InputXf{}, addend);
-        case OFASR_F16: return launch_gemm<f16_t>(name, x, wv, y, N, HW, st, InputXf{}, addend);
-        default: return launch_gemm<bf16_t>(name, x, wv, y, N, HW, st, InputXf{}, addend);
+        case OFASR_F32: return launch_gemm<float>(name, x, wv, y, N, HW, st, InputXf{}, addend, so);
+        case OFASR_F16: return launch_gemm<f16_t>(name, x, wv, y, N, HW, st, InputXf{}, addend, so);
+        default: return launch_gemm<bf16_t>(name, x, wv, y, N, HW, st, InputXf{}, addend, so);
     }
 }
 
@@ -885,8 +956,23 @@ bool pwconv_xf_supported(const void* x, const void* y, int64_t HW, int dtype) {
     return (dtype == OFASR_F16 || dtype == OFASR_BF16) && aligned_for(x, y, HW, true);
 }
 
+int pwconv_stat_units(int64_t N, int64_t Cin, int64_t HW) {
+    const int64_t tiles = N * cdiv(HW, PW_TILE);
+    return (int)(Cin <= 64 ? tiles : 2 * tiles);
+}
+
+int pwconv_fwd_stat(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin, int64_t Cout,
+                    int64_t HW, int dtype, StatOut so, void* stream) {
+    const char* name = "pwconv_fwd_stat";
+    int rc = check_pw_args(name, x, w, y, ldw, N, Cin, Cout, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(so.partial != nullptr && N * HW > 0, OFASR_ERR_INVALID_ARG, "%s: null statistics / empty tensor", name);
+    WView wv{w, ldw, 1, (int)Cout, (int)Cin};
+    return gemm_entry(name, x, wv, y, N, HW, dtype, stream, nullptr, so);
+}
+
 int pwconv_fwd_xf(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t HW,
-                  int dtype, InputXf xf, void* stream) {
+                  int dtype, InputXf xf, void* stream, StatOut so) {
     const char* name = "pwconv_fwd_xf";
     int rc = check_pw_args(name, x, w, y, ldw, N, Cin, Cout, HW, dtype);
     if (rc) return rc;
@@ -895,8 +981,8 @@ int pwconv_fwd_xf(const void* x, const float* w, int64_t ldw, void* y, int64_t N
     if (N * HW == 0) return OFASR_OK;
     WView wv{w, ldw, 1, (int)Cout, (int)Cin};
     hipStream_t st = as_stream(stream);
-    if (dtype == OFASR_F16) return launch_gemm<f16_t, true>(name, x, wv, y, N, HW, st, xf);
-    return launch_gemm<bf16_t, true>(name, x, wv, y, N, HW, st, xf);
+    if (dtype == OFASR_F16) return launch_gemm<f16_t, true>(name, x, wv, y, N, HW, st, xf, nullptr, so);
+    return launch_gemm<bf16_t, true>(name, x, wv, y, N, HW, st, xf, nullptr, so);
 }
 
 int pwconv_wgrad_xf(const void* dy, const void* x, float* dw, int64_t ldw, int64_t N, int64_t Cin, int64_t Cout,
