@@ -551,6 +551,140 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_kernel(const T* __restric
     if (so.partial) stat_epilogue<T, 2>(acc, p0 + 64 * hh + 2 * c, HW, c, h, 32 * cb, mloc, m_base, so, 2 * tile + hh);
 }
 
+// ---- fan-in, 16-bit aligned, vector-loadable weights: the same tile and chunk loop, software-pipelined.  The X and
+// weight chunk of round kc+1 are requested into registers before the MFMAs of round kc, so the LDS fill, the two
+// barriers and the MFMAs of a round hide behind the next chunk's HBM round trip instead of adding to it (measured
+// timeline of the plain loop: ~10 us of loads + 3.4 us of rounds + W latency, nothing overlapped).
+template <typename T, bool XF>
+__global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y,
+                                                                   int HW, int tiles_per_img, int kchunks, InputXf xf,
+                                                                   const T* __restrict__ addend, StatOut so) {
+    __shared__ __attribute__((aligned(16))) char Ws[64 * WROW16];
+    __shared__ __attribute__((aligned(16))) char Xs[64 * XROW16];
+    const int tid = threadIdx.x;
+    const int m_base = blockIdx.y * 64;
+    const int mloc = min(64, wv.M - m_base);
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int c = lane & 31, h = lane >> 5;
+    const int cb = wave & 1, hh = wave >> 1;
+    const int tile = blockIdx.x;
+    const int n = tile / tiles_per_img;
+    const int p0 = (tile - n * tiles_per_img) * PW_TILE;
+    const T* xn = x + (long long)n * wv.K * HW;
+    T* yn = y + ((long long)n * wv.M + m_base) * HW;
+    const bool rowmajor = wv.sk == 1;
+
+    uint4 xr[4];
+    float4 wr[4];
+    auto load_chunk = [&](int kc) {
+        const int k0 = 64 * kc;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {   // weights first: vector-memory returns are in order
+            const int q = tid + it * PW_THREADS;
+            wr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rowmajor) {
+                const int r = q >> 4, kk = k0 + 4 * (q & 15);
+                if (r < mloc) {
+                    const float* src = wv.w + (long long)(m_base + r) * wv.sm + kk;
+                    if (kk + 3 < wv.K) wr[it] = *reinterpret_cast<const float4*>(src);
+                    else {
+                        if (kk < wv.K) wr[it].x = src[0];
+                        if (kk + 1 < wv.K) wr[it].y = src[1];
+                        if (kk + 2 < wv.K) wr[it].z = src[2];
+                    }
+                }
+            } else {
+                const int k = q >> 4, r = 4 * (q & 15);
+                const int m = m_base + r, kk = k0 + k;
+                if (kk < wv.K) {
+                    const float* src = wv.w + (long long)kk * wv.sk + m;
+                    if (m + 3 < wv.M) wr[it] = *reinterpret_cast<const float4*>(src);
+                    else {
+                        if (m < wv.M) wr[it].x = src[0];
+                        if (m + 1 < wv.M) wr[it].y = src[1];
+                        if (m + 2 < wv.M) wr[it].z = src[2];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int q = tid + it * PW_THREADS;
+            const int k = k0 + (q >> 4), px = p0 + 8 * (q & 15);
+            xr[it] = make_uint4(0, 0, 0, 0);
+            if (k < wv.K && px < HW) xr[it] = *reinterpret_cast<const uint4*>(xn + (long long)k * HW + px);
+        }
+    };
+    auto store_chunk = [&](int kc) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int q = tid + it * PW_THREADS;
+            if (rowmajor) {
+                const int r = q >> 4, k = 4 * (q & 15);
+                *reinterpret_cast<uint2*>(Ws + wtile_off<T>(r, k)) =
+                    make_uint2(pack2<T>(wr[it].x, wr[it].y), pack2<T>(wr[it].z, wr[it].w));
+            } else {
+                const int k = q >> 4, r = 4 * (q & 15);
+                lds_store_w<T>(Ws, wtile_off<T>(r, k), wr[it].x);
+                lds_store_w<T>(Ws, wtile_off<T>(r + 1, k), wr[it].y);
+                lds_store_w<T>(Ws, wtile_off<T>(r + 2, k), wr[it].z);
+                lds_store_w<T>(Ws, wtile_off<T>(r + 3, k), wr[it].w);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int q = tid + it * PW_THREADS;
+            const int k = q >> 4, m = q & 15;
+            uint4 v = xr[it];
+            if constexpr (XF) {
+                if (64 * kc + k < wv.K && p0 + 8 * m < HW) v = xf_apply8<T>(v, xf, 64 * kc + k);
+            }
+            // pixel 8m+i -> position 64*(m>>3) + 32*(i&1) + 4*(m&7) + (i>>1)   (stage_x_tile, PX = 2)
+            char* rowp = Xs + k * XROW16;
+            const int base = 64 * (m >> 3) + 4 * (m & 7);
+            *reinterpret_cast<uint2*>(rowp + base * 2) =
+                make_uint2((v.x & 0xffffu) | (v.y << 16), (v.z & 0xffffu) | (v.w << 16));
+            *reinterpret_cast<uint2*>(rowp + (base + 32) * 2) =
+                make_uint2((v.x >> 16) | (v.y & 0xffff0000u), (v.z >> 16) | (v.w & 0xffff0000u));
+        }
+    };
+
+    f32x16 acc[2];
+    acc[0] = zero16();
+    acc[1] = zero16();
+    const int row = 32 * cb + c;
+    auto mma_round = [&]() {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const s16x8 af = *reinterpret_cast<const s16x8*>(Ws + wtile_chunk_off<T>(row, 2 * s + h));
+            const s16x8 b0 = read_b_frag16(Xs, 64 * hh, s, lane);
+            const s16x8 b1 = read_b_frag16(Xs, 64 * hh + 32, s, lane);
+            acc[0] = Mma16<T>::run(af, b0, acc[0]);
+            acc[1] = Mma16<T>::run(af, b1, acc[1]);
+        }
+    };
+    load_chunk(0);
+    for (int kc = 0; kc < kchunks; ++kc) {
+        if (kc) __syncthreads();   // the previous round's readers are done with Ws / Xs
+        store_chunk(kc);
+        __syncthreads();
+        if (kc + 1 < kchunks) load_chunk(kc + 1);   // in flight during this round's MFMAs and the next barrier
+        mma_round();
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int r = 32 * cb + acc_row(reg, h);
+        if (r < mloc) {
+            float v[2] = {acc[0][reg], acc[1][reg]};
+            if (addend)
+                add_px<T, 2, true>(addend + ((long long)n * wv.M + m_base + r) * HW, p0 + 64 * hh + 2 * c, HW, v);
+            store_px<T, 2, true>(yn + (long long)r * HW, p0 + 64 * hh + 2 * c, HW, v);
+        }
+    }
+    if (so.partial) stat_epilogue<T, 2>(acc, p0 + 64 * hh + 2 * c, HW, c, h, 32 * cb, mloc, m_base, so, 2 * tile + hh);
+}
+
 // -------------------------------------------------------------------------------------- wgrad
 // out(r, s) = sum_{n,p} R[n][r][p] * S[n][s][p];  R: [N][MR][HW], S: [N][NS][HW].
 // block: 64 R-rows x 64 S-rows, one 32x32 MFMA tile per wave; grid.z splits the (n, pixel-chunk) range;
@@ -832,6 +966,11 @@ static void launch_gemm_v(const void* x, WView wv, void* y, int64_t HW, int tile
                            (int)HW, tiles_per_img, xf, (const T*)addend, so);
     } else {
         dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, 64));
+        if constexpr (Elem<T>::is16 && AL && WV) {
+            hipLaunchKernelGGL((pw_fanin_pipe_kernel<T, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
+                               (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf, (const T*)addend, so);
+            return;
+        }
         hipLaunchKernelGGL((pw_fanin_kernel<T, AL, WV, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
                            (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf, (const T*)addend, so);
     }
