@@ -210,7 +210,7 @@ def kernel_symbol(call):
     """HIP kernel run by a single-launch API call of the timer table (None for multi-kernel calls)."""
     if call.startswith("pwconv_fwd_") or call.startswith("pwconv_dgrad_"):
         k_red = int(call.split("_")[2].split("to")[0])      # reduction width
-        return "pw_fanout_kernel" if k_red <= 64 else "pw_fanin_kernel"
+        return "pw_fanout_kernel" if k_red <= 64 else "pw_fanin_pipe_kernel"   # 16-bit aligned path
     if call.startswith("dwconv_fwd_k") or call.startswith("dwconv_dgrad_k"):
         return "dw_vec_kernel<K=%s>" % call.rsplit("k", 1)[1]
     return {"pixel_shuffle": "ps_r2_kernel", "pixel_unshuffle": "ps_r2_kernel"}.get(call)
