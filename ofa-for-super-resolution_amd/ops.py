@@ -356,8 +356,10 @@ class BNActFn(Function):
         L = _C.lib()
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dgamma = torch.zeros(wshape, dtype=torch.float32, device=x.device)
-        dbeta = torch.zeros(wshape, dtype=torch.float32, device=x.device)
+        # the kernel writes channels [0, C); only a sliced BN (C < num_features) needs the zero tail
+        full = int(wshape[0]) == C
+        gb = (torch.empty if full else torch.zeros)((2,) + tuple(wshape), dtype=torch.float32, device=x.device)
+        dgamma, dbeta = gb[0], gb[1]
         dres = None
         if has_res:
             # without an activation the residual gradient IS dy; with one it is the masked dy
