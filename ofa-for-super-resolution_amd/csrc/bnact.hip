@@ -178,7 +178,9 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(const double* __restric
 // y = act(x*scale[c] + shift[c] (+ res));  act: 0 none, 1 relu6.   grid = (C, N-chunks)
 // where the per-channel statistics of a forward apply pass come from
 struct BnSource {
-    int mode;                 // 0: given (scale, shift, mean);  1: train, from stats partials;  2: eval, running stats
+    int mode;                 // 0: given (scale, shift, mean);  1: train, from stats partials;  2: eval, running stats;
+                              // 3: train, from the conv kernels' epilogue partials (StatOut: float2 [C][Pstat])
+    const float2* cp;         // mode 3
     const double* partial;    // mode 1: [Pstat][C][2]
     int Pstat;
     double M, momentum, eps;
@@ -205,7 +207,25 @@ __global__ void __launch_bounds__(BN_THREADS) bn_act_fwd_kernel(const T* __restr
     } else {
         // every block folds the (tiny) finalize into itself: no separate launch between the passes
         double mean, var;
-        if (src.mode == 1) {
+        if (src.mode == 3) {
+            // up to ~1000 partials per channel: the block sums them cooperatively (fixed order), then broadcasts
+            __shared__ double bc[2];
+            double s = 0.0, ss = 0.0;
+            for (int q = threadIdx.x; q < src.Pstat; q += BN_THREADS) {
+                const float2 v = src.cp[(long long)c * src.Pstat + q];
+                s += (double)v.x;
+                ss += (double)v.y;
+            }
+            block_reduce2(s, ss);
+            if (threadIdx.x == 0) {
+                bc[0] = s;
+                bc[1] = ss;
+            }
+            __syncthreads();
+            mean = bc[0] / src.M;
+            var = bc[1] / src.M - mean * mean;
+            if (var < 0.0) var = 0.0;
+        } else if (src.mode == 1) {
             double s = 0.0, ss = 0.0;
             for (int q = 0; q < src.Pstat; ++q) {
                 s += src.partial[((long long)q * C + c) * 2];
@@ -228,7 +248,7 @@ __global__ void __launch_bounds__(BN_THREADS) bn_act_fwd_kernel(const T* __restr
             src.invstd[c] = (float)invstd;
             src.scale[c] = sc;
             src.shift[c] = (float)(b - mean * g * invstd);
-            if (src.mode == 1 && src.running_mean) {
+            if ((src.mode == 1 || src.mode == 3) && src.running_mean) {
                 const double unb = src.M > 1.0 ? var * src.M / (src.M - 1.0) : var;
                 src.running_mean[c] = (float)((1.0 - src.momentum) * (double)src.running_mean[c] + src.momentum * mean);
                 src.running_var[c] = (float)((1.0 - src.momentum) * (double)src.running_var[c] + src.momentum * unb);
@@ -472,7 +492,38 @@ OFASR_EXPORT int ofasr_bn_finalize(const void* workspace, int64_t n_partials, in
     return check_launch(name);
 }
 
+static int launch_bn_apply(const char* name, const void* x, const void* residual, void* y, const BnSource& src,
+                           int64_t N, int64_t C, int64_t HW, int act, int dtype, void* stream);
 namespace ofasr {
+// BatchNorm (+act)(+residual) forward whose statistics come from conv-epilogue partials: the finalize is folded into
+// every block of the apply kernel (no finalize launch).  training == 0: running statistics.
+int bn_fwd_cp(const void* x, const void* residual, void* y, const float2* partial, int64_t P, const float* gamma,
+              const float* beta, float* running_mean, float* running_var, double momentum, double eps, int training,
+              float* stats, int64_t N, int64_t C, int64_t HW, int act, int dtype, void* stream) {
+    const char* name = "bn_fwd_cp";
+    int rc = check_bn(name, N, C, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(x && y && stats, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(training ? (partial != nullptr && P > 0) : (running_mean && running_var), OFASR_ERR_INVALID_ARG,
+                  "%s: missing statistics source", name);
+    BnSource src{};
+    src.mode = training ? 3 : 2;
+    src.cp = partial;
+    src.Pstat = (int)P;
+    src.M = (double)N * (double)HW;
+    src.momentum = momentum;
+    src.eps = eps;
+    src.gamma = gamma;
+    src.beta = beta;
+    src.running_mean = running_mean;
+    src.running_var = running_var;
+    src.mean = stats;
+    src.invstd = stats + C;
+    src.scale = stats + 2 * C;
+    src.shift = stats + 3 * C;
+    return launch_bn_apply(name, x, residual, y, src, N, C, HW, act, dtype, stream);
+}
+
 // one wave per channel: lane l sums partials l, l+64, ... in fp64, then a fixed-order butterfly
 __global__ void __launch_bounds__(64) bn_finalize_cp_kernel(const float2* __restrict__ partial, int P, int C, double M,
                                                             const float* __restrict__ gamma,

@@ -248,9 +248,13 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
                            xf_of(stat_buf, 1, d->mid, d->Cout), stream,
                            StatOut{(pw_stat && d->bn_training[2]) ? part : nullptr, P3});
         if (rc) return rc;
-        rc = pw_stat ? finalize(2, d->Cout, P3, false) : pass_stats(2, y3, d->Cout, false);
-        if (rc) return rc;
         StatView s3 = stat_view(stat_buf, 2, d->mid, d->Cout);
+        if (pw_stat)   // BN3's finalize is folded into the apply kernel's blocks
+            return bn_fwd_cp(y3, d->residual ? x : nullptr, out, part, P3, d->gamma[2], d->beta[2], d->running_mean[2],
+                             d->running_var[2], d->bn_momentum[2], d->bn_eps[2], d->bn_training[2], s3.mean, d->N,
+                             d->Cout, HW, 0, d->dtype, stream);
+        rc = pass_stats(2, y3, d->Cout, false);
+        if (rc) return rc;
         return ofasr_bn_act_fwd(y3, d->residual ? x : nullptr, out, s3.scale, s3.shift, s3.mean, d->N, d->Cout, HW, 0,
                                 d->dtype, stream);
     }

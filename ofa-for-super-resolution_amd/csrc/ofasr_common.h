@@ -109,6 +109,10 @@ int bn_finalize_cp(const float2* partial, int64_t P, int64_t C, double count, co
                    float* running_mean, float* running_var, double momentum, double eps, int training, float* mean,
                    float* invstd, float* scale, float* shift, int64_t* k0, int64_t* k1, int64_t* k2, void* stream);
 
+int bn_fwd_cp(const void* x, const void* residual, void* y, const float2* partial, int64_t P, const float* gamma,
+              const float* beta, float* running_mean, float* running_var, double momentum, double eps, int training,
+              float* stats, int64_t N, int64_t C, int64_t HW, int act, int dtype, void* stream);
+
 // internal (not exported) variants used by mbconv.hip; they return OFASR_ERR_UNSUPPORTED (and launch nothing) when
 // the vector / aligned 16-bit kernels that implement the fused read do not apply to the shape.
 bool dwconv_xf_supported(const void* x, const void* y, int64_t H, int64_t W, int K, int dtype);
