@@ -24,6 +24,7 @@ struct MbSizes {
     size_t ws_pw;
     size_t ws_kt;
     size_t scratch;       // main-stream region shared by whichever BN kernel is running
+    size_t stat_a;        // bytes of the first statistics-partials region inside it (BN1 / BN3); BN2's follows
     size_t side;          // side-stream region shared by whichever weight-gradient kernel is running
     size_t df_bytes;      // depthwise filter gradient (lives from dw wgrad to the kernel-transform backward)
     size_t total;
@@ -51,9 +52,9 @@ static MbSizes mb_sizes(const ofasr_mbconv_desc* d) {
         const size_t u1 = (size_t)pwconv_stat_units(d->N, d->Cin, HW) * (size_t)d->mid;
         const size_t u2 = (size_t)dwconv_stat_units(d->N, d->H, d->W, d->K, d->dtype) * (size_t)d->mid;
         const size_t u3 = (size_t)pwconv_stat_units(d->N, d->mid, HW) * (size_t)d->Cout;
-        size_t u = u1 > u2 ? u1 : u2;
-        u = u > u3 ? u : u3;
-        const size_t ws_stat = align_up(u * sizeof(float2), 256);
+        // two regions: a consumer that folds its input's partials (region B) writes its own output's partials (region A)
+        s.stat_a = align_up((u1 > u3 ? u1 : u3) * sizeof(float2), 256);
+        const size_t ws_stat = s.stat_a + align_up(u2 * sizeof(float2), 256);
         if (ws_stat > s.scratch) s.scratch = ws_stat;
     }
     s.side = s.ws_dw > s.ws_pw ? s.ws_dw : s.ws_pw;
@@ -207,7 +208,8 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
         // per-channel finalize turns them into scale/shift (+ running statistics, + the three counters): no pass over
         // the tensors for statistics, no pass for BN1/BN2 + ReLU6 (applied by the consumer's loads)
         const double count = (double)d->N * (double)HW;
-        float2* part = (float2*)workspace;
+        float2* part = (float2*)workspace;                              // BN1 and BN3 partials
+        float2* part_b = (float2*)((char*)workspace + s.stat_a);       // BN2 partials
         auto finalize = [&](int which, int64_t C, int P, bool bump) -> int {
             StatView sv = stat_view(stat_buf, which, d->mid, d->Cout);
             int64_t* k[3] = {nullptr, nullptr, nullptr};
@@ -240,13 +242,25 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
         rc = ofasr_ktransform_fwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, f, d->mid, stream);
         if (rc) return rc;
         rc = dwconv_fwd_xf(y1, f, y2, d->N, d->mid, d->H, d->W, d->K, d->dtype, xf_of(stat_buf, 0, d->mid, d->Cout),
-                           stream, StatOut{d->bn_training[1] ? part : nullptr, P2});
+                           stream, StatOut{d->bn_training[1] ? part_b : nullptr, P2});
         if (rc) return rc;
-        rc = finalize(1, d->mid, P2, false);
-        if (rc) return rc;
-        rc = pwconv_fwd_xf(y2, d->w2, d->ldw2, y3, d->N, d->mid, d->Cout, HW, d->dtype,
-                           xf_of(stat_buf, 1, d->mid, d->Cout), stream,
-                           StatOut{(pw_stat && d->bn_training[2]) ? part : nullptr, P3});
+        const StatOut so3{(pw_stat && d->bn_training[2]) ? part : nullptr, P3};
+        if (d->bn_training[1] && pwconv_fold_supported(y2, y3, d->w2, d->ldw2, d->mid, HW, d->dtype)) {
+            // BN2's finalize is folded into the project kernel's blocks (16 partials per channel)
+            StatView sv = stat_view(stat_buf, 1, d->mid, d->Cout);
+            rc = pwconv_fwd_fold(y2, d->w2, d->ldw2, y3, d->N, d->mid, d->Cout, HW, d->dtype,
+                                 BnFold{part_b, P2, count, d->bn_momentum[1], d->bn_eps[1], d->gamma[1], d->beta[1],
+                                        d->running_mean[1], d->running_var[1], sv.mean, sv.invstd, sv.scale, sv.shift},
+                                 stream, so3);
+        } else {
+            float2* keep = part;
+            part = part_b;
+            rc = finalize(1, d->mid, P2, false);
+            part = keep;
+            if (rc) return rc;
+            rc = pwconv_fwd_xf(y2, d->w2, d->ldw2, y3, d->N, d->mid, d->Cout, HW, d->dtype,
+                               xf_of(stat_buf, 1, d->mid, d->Cout), stream, so3);
+        }
         if (rc) return rc;
         StatView s3 = stat_view(stat_buf, 2, d->mid, d->Cout);
         if (pw_stat)   // BN3's finalize is folded into the apply kernel's blocks

@@ -94,6 +94,24 @@ struct InputXf {
     const float* mean;
 };
 
+// A consumer kernel can fold the producer's epilogue partials itself (no finalize launch between the two): every
+// block derives scale / mean / beta of the channels it reads from partial[c * P + 0..P) in fp64 in a fixed order, and
+// one designated block also writes mean | invstd | scale | shift (kept for the backward) and the running statistics.
+// cp == nullptr: not used (the InputXf pointers hold finalized values).
+struct BnFold {
+    const float2* cp;
+    int P;
+    double M, momentum, eps;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    float* mean;
+    float* invstd;
+    float* scale;
+    float* shift;
+};
+
 // Optional BatchNorm statistics of the tensor a conv kernel writes: every producer unit p (a pixel tile, a plane slab)
 // leaves its per-channel (sum, sum of squares) at partial[c * P + p] -- fp32 over <= a few thousand values -- and
 // bn_finalize_cp folds the P partials of a channel in fp64 in a fixed order.  partial == nullptr: no statistics.
@@ -131,6 +149,10 @@ int pwconv_dgrad_add(const void* dy, const float* w, int64_t ldw, void* dx, cons
 bool pwconv_xf_supported(const void* x, const void* y, int64_t HW, int dtype);
 int pwconv_fwd_xf(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t HW,
                   int dtype, InputXf xf, void* stream, StatOut so = StatOut{nullptr, 0});
+// the same with the input BN's finalize folded into the kernel; only for the shapes pwconv_fold_supported accepts
+bool pwconv_fold_supported(const void* x, const void* y, const float* w, int64_t ldw, int64_t Cin, int64_t HW, int dtype);
+int pwconv_fwd_fold(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin, int64_t Cout,
+                    int64_t HW, int dtype, BnFold fold, void* stream, StatOut so = StatOut{nullptr, 0});
 // plain forward (no input transform) that leaves the output's statistics partials
 int pwconv_fwd_stat(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin, int64_t Cout,
                     int64_t HW, int dtype, StatOut so, void* stream);

@@ -181,8 +181,14 @@ __device__ __forceinline__ int pos16(int q) {
 
 // fused BN + ReLU6 of 8 packed 16-bit values of channel ch (InputXf, ofasr_common.h)
 template <typename T>
+__device__ __forceinline__ uint4 xf_apply8_core(uint4 v, float sc, float mu, float b);
+template <typename T>
 __device__ __forceinline__ uint4 xf_apply8(uint4 v, const InputXf& xf, int ch) {
-    const float sc = xf.scale[ch], mu = xf.mean[ch], b = fmaf(mu, sc, xf.shift[ch]);
+    const float sc = xf.scale[ch], mu = xf.mean[ch];
+    return xf_apply8_core<T>(v, sc, mu, fmaf(mu, sc, xf.shift[ch]));
+}
+template <typename T>
+__device__ __forceinline__ uint4 xf_apply8_core(uint4 v, float sc, float mu, float b) {
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -555,13 +561,52 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_kernel(const T* __restric
 // weight chunk of round kc+1 are requested into registers before the MFMAs of round kc, so the LDS fill, the two
 // barriers and the MFMAs of a round hide behind the next chunk's HBM round trip instead of adding to it (measured
 // timeline of the plain loop: ~10 us of loads + 3.4 us of rounds + W latency, nothing overlapped).
+constexpr int FOLD_KMAX = 512;   // input channels a block can fold statistics for (3 LDS tables)
 template <typename T, bool XF>
 __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y,
                                                                    int HW, int tiles_per_img, int kchunks, InputXf xf,
-                                                                   const T* __restrict__ addend, StatOut so) {
+                                                                   const T* __restrict__ addend, StatOut so,
+                                                                   BnFold fold = BnFold{}) {
     __shared__ __attribute__((aligned(16))) char Ws[64 * WROW16];
     __shared__ __attribute__((aligned(16))) char Xs[64 * XROW16];
+    __shared__ float fsc[XF ? FOLD_KMAX : 1], fmu[XF ? FOLD_KMAX : 1], fb[XF ? FOLD_KMAX : 1];
     const int tid = threadIdx.x;
+    const bool folded = XF && fold.cp != nullptr;
+    if constexpr (XF) {
+        if (folded) {   // the input BN's finalize, per block: channel ch from its P partials, fixed order, fp64
+            const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+            for (int ch = tid; ch < wv.K; ch += PW_THREADS) {
+                double s = 0.0, ss = 0.0;
+                for (int q = 0; q < fold.P; ++q) {
+                    const float2 v = fold.cp[(long long)ch * fold.P + q];
+                    s += (double)v.x;
+                    ss += (double)v.y;
+                }
+                const double mean = s / fold.M;
+                double var = ss / fold.M - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                const double invstd = 1.0 / sqrt(var + fold.eps);
+                const double g = fold.gamma ? (double)fold.gamma[ch] : 1.0, b = fold.beta ? (double)fold.beta[ch] : 0.0;
+                fsc[ch] = (float)(g * invstd);
+                fmu[ch] = (float)mean;
+                fb[ch] = (float)b;
+                if (writer) {
+                    fold.mean[ch] = (float)mean;
+                    fold.invstd[ch] = (float)invstd;
+                    fold.scale[ch] = (float)(g * invstd);
+                    fold.shift[ch] = (float)(b - mean * g * invstd);
+                    if (fold.running_mean) {
+                        const double unb = fold.M > 1.0 ? var * fold.M / (fold.M - 1.0) : var;
+                        fold.running_mean[ch] =
+                            (float)((1.0 - fold.momentum) * (double)fold.running_mean[ch] + fold.momentum * mean);
+                        fold.running_var[ch] =
+                            (float)((1.0 - fold.momentum) * (double)fold.running_var[ch] + fold.momentum * unb);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
     const int m_base = blockIdx.y * 64;
     const int mloc = min(64, wv.M - m_base);
     const int lane = lane_id();
@@ -638,7 +683,10 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __re
             const int k = q >> 4, m = q & 15;
             uint4 v = xr[it];
             if constexpr (XF) {
-                if (64 * kc + k < wv.K && p0 + 8 * m < HW) v = xf_apply8<T>(v, xf, 64 * kc + k);
+                if (64 * kc + k < wv.K && p0 + 8 * m < HW) {
+                    const int ch = 64 * kc + k;
+                    v = folded ? xf_apply8_core<T>(v, fsc[ch], fmu[ch], fb[ch]) : xf_apply8<T>(v, xf, ch);
+                }
             }
             // pixel 8m+i -> position 64*(m>>3) + 32*(i&1) + 4*(m&7) + (i>>1)   (stage_x_tile, PX = 2)
             char* rowp = Xs + k * XROW16;
@@ -959,7 +1007,7 @@ static bool aligned_for(const void* a, const void* b, int64_t HW, bool is16) {
 template <typename T, bool AL, bool WV, bool XF = false>
 static void launch_gemm_v(const void* x, WView wv, void* y, int64_t HW, int tiles_per_img, int total_tiles,
                           hipStream_t st, InputXf xf = InputXf{}, const void* addend = nullptr,
-                          StatOut so = StatOut{nullptr, 0}) {
+                          StatOut so = StatOut{nullptr, 0}, BnFold fold = BnFold{}) {
     if (wv.K <= 64) {
         dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, FO_ROWS));
         hipLaunchKernelGGL((pw_fanout_kernel<T, AL, WV, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
@@ -968,7 +1016,7 @@ static void launch_gemm_v(const void* x, WView wv, void* y, int64_t HW, int tile
         dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, 64));
         if constexpr (Elem<T>::is16 && AL && WV) {
             hipLaunchKernelGGL((pw_fanin_pipe_kernel<T, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
-                               (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf, (const T*)addend, so);
+                               (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf, (const T*)addend, so, fold);
             return;
         }
         hipLaunchKernelGGL((pw_fanin_kernel<T, AL, WV, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
@@ -978,7 +1026,8 @@ static void launch_gemm_v(const void* x, WView wv, void* y, int64_t HW, int tile
 
 template <typename T, bool XF = false>
 static int launch_gemm(const char* name, const void* x, WView wv, void* y, int64_t N, int64_t HW, hipStream_t st,
-                       InputXf xf = InputXf{}, const void* addend = nullptr, StatOut so = StatOut{nullptr, 0}) {
+                       InputXf xf = InputXf{}, const void* addend = nullptr, StatOut so = StatOut{nullptr, 0},
+                       BnFold fold = BnFold{}) {
     constexpr bool is16 = Elem<T>::is16;
     const bool al = aligned_for(x, y, HW, is16);
     const long long ld = wv.sk == 1 ? wv.sm : wv.sk;
@@ -992,7 +1041,10 @@ static int launch_gemm(const char* name, const void* x, WView wv, void* y, int64
                       "%s: statistics unit count %d does not match the launch", name, so.P);
     if constexpr (XF) {
         OFASR_REQUIRE(al && is16, OFASR_ERR_UNSUPPORTED, "%s: fused input transform needs aligned 16-bit tensors", name);
-        if (wvec) launch_gemm_v<T, true, true, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, xf, nullptr, so);
+        if (fold.cp)
+            OFASR_REQUIRE(wvec && wv.K > 64 && wv.K <= FOLD_KMAX, OFASR_ERR_UNSUPPORTED,
+                          "%s: folded statistics need the pipelined fan-in kernel (64 < K <= %d)", name, FOLD_KMAX);
+        if (wvec) launch_gemm_v<T, true, true, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, xf, nullptr, so, fold);
         else launch_gemm_v<T, true, false, true>(x, wv, y, HW, tiles_per_img, total_tiles, st, xf, nullptr, so);
         return check_launch(name);
     }
@@ -1108,6 +1160,26 @@ int pwconv_fwd_stat(const void* x, const float* w, int64_t ldw, void* y, int64_t
     OFASR_REQUIRE(so.partial != nullptr && N * HW > 0, OFASR_ERR_INVALID_ARG, "%s: null statistics / empty tensor", name);
     WView wv{w, ldw, 1, (int)Cout, (int)Cin};
     return gemm_entry(name, x, wv, y, N, HW, dtype, stream, nullptr, so);
+}
+
+bool pwconv_fold_supported(const void* x, const void* y, const float* w, int64_t ldw, int64_t Cin, int64_t HW, int dtype) {
+    const bool wvec = (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (ldw % 4) == 0;
+    return pwconv_xf_supported(x, y, HW, dtype) && wvec && Cin > 64 && Cin <= FOLD_KMAX;
+}
+
+int pwconv_fwd_fold(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin, int64_t Cout,
+                    int64_t HW, int dtype, BnFold fold, void* stream, StatOut so) {
+    const char* name = "pwconv_fwd_fold";
+    int rc = check_pw_args(name, x, w, y, ldw, N, Cin, Cout, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(fold.cp && fold.P > 0 && fold.mean && fold.invstd && fold.scale && fold.shift, OFASR_ERR_INVALID_ARG,
+                  "%s: incomplete statistics source", name);
+    OFASR_REQUIRE(dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_UNSUPPORTED, "%s: 16-bit only", name);
+    OFASR_REQUIRE(N * HW > 0, OFASR_ERR_UNSUPPORTED, "%s: empty tensor", name);
+    WView wv{w, ldw, 1, (int)Cout, (int)Cin};
+    hipStream_t st = as_stream(stream);
+    if (dtype == OFASR_F16) return launch_gemm<f16_t, true>(name, x, wv, y, N, HW, st, InputXf{}, nullptr, so, fold);
+    return launch_gemm<bf16_t, true>(name, x, wv, y, N, HW, st, InputXf{}, nullptr, so, fold);
 }
 
 int pwconv_fwd_xf(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t HW,
