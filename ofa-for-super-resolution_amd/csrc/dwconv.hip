@@ -303,7 +303,7 @@ template <typename T, int K, bool FLIP, bool XF = false, bool STAT = false>
 __global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restrict__ x, const float* __restrict__ f,
                                                                T* __restrict__ y, int C, int H, int W, VecGeom vg,
                                                                long long nwaves, InputXf xf = InputXf{},
-                                                               StatOut so = StatOut{nullptr, 0}) {
+                                                               StatOut so = StatOut{nullptr, 0}, BnFold fold = BnFold{}) {
     constexpr int PAD = K / 2;
     constexpr int PXL = VecPx<T, K>::N;
     typedef PxIO<T, PXL> IO;
@@ -321,9 +321,49 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restri
     for (int e = 0; e < K * K; ++e) taps[e] = f[(long long)c * K * K + (FLIP ? (K * K - 1 - e) : e)];
     float xsc = 1.f, xmu = 0.f, xb = 0.f;            // fused BN + ReLU6 of the input plane (wave-uniform)
     if constexpr (XF) {
-        xsc = xf.scale[c];
-        xmu = xf.mean[c];
-        xb = fmaf(xmu, xsc, xf.shift[c]);
+        if (fold.cp) {
+            // the input BN's finalize, per wave: channel c from its P partials (lanes stride, fp64 butterfly: fixed order)
+            double s = 0.0, ss = 0.0;
+            for (int q = lane; q < fold.P; q += 64) {
+                const float2 v = fold.cp[(long long)c * fold.P + q];
+                s += (double)v.x;
+                ss += (double)v.y;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                s += __shfl_xor(s, o, 64);
+                ss += __shfl_xor(ss, o, 64);
+            }
+            const double mean = s / fold.M;
+            double var = ss / fold.M - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double invstd = 1.0 / sqrt(var + fold.eps);
+            const double gm = fold.gamma ? (double)fold.gamma[c] : 1.0, bt = fold.beta ? (double)fold.beta[c] : 0.0;
+            xsc = (float)(gm * invstd);
+            xmu = (float)mean;
+            xb = (float)bt;
+            if (plane < C && slab == 0 && lane == 0) {   // image 0's wave of channel c keeps the statistics
+                fold.mean[c] = (float)mean;
+                fold.invstd[c] = (float)invstd;
+                fold.scale[c] = xsc;
+                fold.shift[c] = (float)(bt - mean * gm * invstd);
+                if (fold.running_mean) {
+                    const double unb = fold.M > 1.0 ? var * fold.M / (fold.M - 1.0) : var;
+                    fold.running_mean[c] =
+                        (float)((1.0 - fold.momentum) * (double)fold.running_mean[c] + fold.momentum * mean);
+                    fold.running_var[c] = (float)((1.0 - fold.momentum) * (double)fold.running_var[c] + fold.momentum * unb);
+                }
+                if (c == 0) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        if (fold.counters[i]) *fold.counters[i] += 1;
+                }
+            }
+        } else {
+            xsc = xf.scale[c];
+            xmu = xf.mean[c];
+            xb = fmaf(xmu, xsc, xf.shift[c]);
+        }
     }
 
     const int g = lane / vg.G, gl = lane - g * vg.G;
@@ -541,7 +581,8 @@ static int wgrad_parts(int64_t N, int64_t C) {
 
 template <typename T, bool FLIP, bool XF = false, bool STAT = false>
 static int launch_conv(const char* name, const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H,
-                       int64_t W, int K, hipStream_t st, InputXf xf = InputXf{}, StatOut so = StatOut{nullptr, 0}) {
+                       int64_t W, int K, hipStream_t st, InputXf xf = InputXf{}, StatOut so = StatOut{nullptr, 0},
+                       BnFold fold = BnFold{}) {
     {
         VecGeom vg;
 #define OFASR_DWV(KK)                                                                                               \
@@ -553,7 +594,7 @@ static int launch_conv(const char* name, const void* x, const float* f, void* y,
         }                                                                                                          \
         hipLaunchKernelGGL((dw_vec_kernel<T, KK, FLIP, XF, STAT>), dim3((unsigned)cdiv(nwaves, DW_WAVES)),         \
                            dim3(64 * DW_WAVES), 0, st, (const T*)x, f, (T*)y, (int)C, (int)H, (int)W, vg, nwaves,  \
-                           xf, so);                                                                                \
+                           xf, so, fold);                                                                          \
         return check_launch(name);                                                                                 \
     }
         switch (K) {
@@ -681,20 +722,24 @@ int dwconv_stat_units(int64_t N, int64_t H, int64_t W, int K, int dtype) {
 }
 
 int dwconv_fwd_xf(const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H, int64_t W, int K, int dtype,
-                  InputXf xf, void* stream, StatOut so) {
+                  InputXf xf, void* stream, StatOut so, BnFold fold) {
     const char* name = "dwconv_fwd_xf";
     int rc = check_conv_args(name, x, f, y, N, C, H, W, K, dtype);
     if (rc) return rc;
-    OFASR_REQUIRE(xf.scale && xf.shift && xf.mean, OFASR_ERR_INVALID_ARG, "%s: null transform", name);
+    OFASR_REQUIRE((xf.scale && xf.shift && xf.mean) ||
+                      (fold.cp && fold.P > 0 && fold.mean && fold.invstd && fold.scale && fold.shift),
+                  OFASR_ERR_INVALID_ARG, "%s: null transform", name);
     OFASR_REQUIRE(dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_UNSUPPORTED, "%s: 16-bit only", name);
     if (N * C * H * W == 0) return OFASR_OK;
     hipStream_t st = as_stream(stream);
     if (so.partial) {
-        if (dtype == OFASR_F16) return launch_conv<f16_t, false, true, true>(name, x, f, y, N, C, H, W, K, st, xf, so);
-        return launch_conv<bf16_t, false, true, true>(name, x, f, y, N, C, H, W, K, st, xf, so);
+        if (dtype == OFASR_F16)
+            return launch_conv<f16_t, false, true, true>(name, x, f, y, N, C, H, W, K, st, xf, so, fold);
+        return launch_conv<bf16_t, false, true, true>(name, x, f, y, N, C, H, W, K, st, xf, so, fold);
     }
-    if (dtype == OFASR_F16) return launch_conv<f16_t, false, true>(name, x, f, y, N, C, H, W, K, st, xf);
-    return launch_conv<bf16_t, false, true>(name, x, f, y, N, C, H, W, K, st, xf);
+    if (dtype == OFASR_F16)
+        return launch_conv<f16_t, false, true>(name, x, f, y, N, C, H, W, K, st, xf, StatOut{nullptr, 0}, fold);
+    return launch_conv<bf16_t, false, true>(name, x, f, y, N, C, H, W, K, st, xf, StatOut{nullptr, 0}, fold);
 }
 
 int dwconv_wgrad_xf(const void* dy, const void* x, float* df, int64_t N, int64_t C, int64_t H, int64_t W, int K,

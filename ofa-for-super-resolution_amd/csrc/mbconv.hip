@@ -237,12 +237,25 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
                                     d->bn_eps[which], d->bn_training[which], sv.mean, sv.invstd, sv.scale, sv.shift,
                                     k[0], k[1], k[2], stream);
         };
-        rc = pw_stat ? finalize(0, d->mid, P1, true) : pass_stats(0, y1, d->mid, true);
-        if (rc) return rc;
+        const bool fold1 = pw_stat && d->bn_training[0];   // BN1's finalize folded into the depthwise kernel's waves
+        if (!fold1) {
+            rc = pw_stat ? finalize(0, d->mid, P1, true) : pass_stats(0, y1, d->mid, true);
+            if (rc) return rc;
+        }
         rc = ofasr_ktransform_fwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, f, d->mid, stream);
         if (rc) return rc;
-        rc = dwconv_fwd_xf(y1, f, y2, d->N, d->mid, d->H, d->W, d->K, d->dtype, xf_of(stat_buf, 0, d->mid, d->Cout),
-                           stream, StatOut{d->bn_training[1] ? part_b : nullptr, P2});
+        {
+            StatView sv = stat_view(stat_buf, 0, d->mid, d->Cout);
+            BnFold f1{};
+            if (fold1) {
+                f1 = BnFold{part, P1, count, d->bn_momentum[0], d->bn_eps[0], d->gamma[0], d->beta[0], d->running_mean[0],
+                            d->running_var[0], sv.mean, sv.invstd, sv.scale, sv.shift, {nullptr, nullptr, nullptr}};
+                for (int i = 0; i < 3; ++i) f1.counters[i] = d->bn_training[i] ? d->num_batches_tracked[i] : nullptr;
+            }
+            rc = dwconv_fwd_xf(y1, f, y2, d->N, d->mid, d->H, d->W, d->K, d->dtype,
+                               fold1 ? InputXf{nullptr, nullptr, nullptr} : xf_of(stat_buf, 0, d->mid, d->Cout), stream,
+                               StatOut{d->bn_training[1] ? part_b : nullptr, P2}, f1);
+        }
         if (rc) return rc;
         const StatOut so3{(pw_stat && d->bn_training[2]) ? part : nullptr, P3};
         if (d->bn_training[1] && pwconv_fold_supported(y2, y3, d->w2, d->ldw2, d->mid, HW, d->dtype)) {
@@ -250,7 +263,8 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
             StatView sv = stat_view(stat_buf, 1, d->mid, d->Cout);
             rc = pwconv_fwd_fold(y2, d->w2, d->ldw2, y3, d->N, d->mid, d->Cout, HW, d->dtype,
                                  BnFold{part_b, P2, count, d->bn_momentum[1], d->bn_eps[1], d->gamma[1], d->beta[1],
-                                        d->running_mean[1], d->running_var[1], sv.mean, sv.invstd, sv.scale, sv.shift},
+                                        d->running_mean[1], d->running_var[1], sv.mean, sv.invstd, sv.scale, sv.shift,
+                                        {nullptr, nullptr, nullptr}},
                                  stream, so3);
         } else {
             float2* keep = part;

@@ -110,6 +110,7 @@ struct BnFold {
     float* invstd;
     float* scale;
     float* shift;
+    int64_t* counters[3];   // num_batches_tracked of the block's BNs, bumped once by the designated writer (may be null)
 };
 
 // Optional BatchNorm statistics of the tensor a conv kernel writes: every producer unit p (a pixel tile, a plane slab)
@@ -135,7 +136,7 @@ int bn_fwd_cp(const void* x, const void* residual, void* y, const float2* partia
 // the vector / aligned 16-bit kernels that implement the fused read do not apply to the shape.
 bool dwconv_xf_supported(const void* x, const void* y, int64_t H, int64_t W, int K, int dtype);
 int dwconv_fwd_xf(const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H, int64_t W, int K, int dtype,
-                  InputXf xf, void* stream, StatOut so = StatOut{nullptr, 0});
+                  InputXf xf, void* stream, StatOut so = StatOut{nullptr, 0}, BnFold fold = BnFold{});
 int dwconv_wgrad_xf(const void* dy, const void* x, float* df, int64_t N, int64_t C, int64_t H, int64_t W, int K,
                     int dtype, InputXf xf, void* workspace, size_t workspace_bytes, void* stream);
 // ofasr_bn_finalize that also bumps up to three num_batches_tracked counters (thread 0)
