@@ -25,8 +25,18 @@ def main():
         agg[n][0] += e - s
         agg[n][1] += 1
     busy = sum(v[0] for v in agg.values()) / 1e6
-    print("steps=%d  wall/step=%.3f ms  gpu-busy/step=%.3f ms  kernels/step=%.0f" % (
-        nsteps, span / nsteps, busy / nsteps, len(sel) / nsteps))
+    # union of the kernel intervals (kernels overlap when the side stream is active): GPU time with >= 1 kernel running
+    union, cur_s, cur_e = 0, None, None
+    for s0, e0, _ in sel:
+        if cur_e is None or s0 > cur_e:
+            if cur_e is not None:
+                union += cur_e - cur_s
+            cur_s, cur_e = s0, e0
+        else:
+            cur_e = max(cur_e, e0)
+    union += (cur_e - cur_s) if cur_e is not None else 0
+    print("steps=%d  wall/step=%.3f ms  gpu-busy/step=%.3f ms (sum of kernel durations)  gpu-active/step=%.3f ms "
+          "(union)  kernels/step=%.0f" % (nsteps, span / nsteps, busy / nsteps, union / 1e6 / nsteps, len(sel) / nsteps))
     for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
         print("%-96s n/step=%6.1f ms/step=%7.3f avg_us=%8.1f" % (n[:96], c / nsteps, t / 1e6 / nsteps, t / 1e3 / c))
 
