@@ -920,6 +920,24 @@ __global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restric
     bool rs[WD_RB];
 #pragma unroll
     for (int rb = 0; rb < WD_RB; ++rb) rs[rb] = row0 + 32 * rb + c < MR;
+    // fused BN + ReLU6 of the x operand: this lane's rows / column are fixed, so are its channel constants
+    float xsc[WD_RB], xmu[WD_RB], xb[WD_RB];
+    float csc = 1.f, cmu = 0.f, cbb = 0.f;
+    if constexpr (XF == 1) {
+#pragma unroll
+        for (int rb = 0; rb < WD_RB; ++rb) {
+            const int ch = min(row0 + 32 * rb + c, MR - 1);
+            xsc[rb] = xf.scale[ch];
+            xmu[rb] = xf.mean[ch];
+            xb[rb] = fmaf(xmu[rb], xsc[rb], xf.shift[ch]);
+        }
+    }
+    if constexpr (XF == 2) {
+        const int ch = min(col, NS - 1);
+        csc = xf.scale[ch];
+        cmu = xf.mean[ch];
+        cbb = fmaf(cmu, csc, xf.shift[ch]);
+    }
     for (int q = q0; q < q1; ++q) {
         const int n = q / wp.quads_per_img;
         const int px = (q - n * wp.quads_per_img) * 64 + 32 * h;   // this lane's first pixel
@@ -930,7 +948,7 @@ __global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restric
             b[j] = make_uint4(0, 0, 0, 0);
             if (cs && px + 8 * j < HW) {
                 b[j] = *reinterpret_cast<const uint4*>(sp + 8 * j);
-                if constexpr (XF == 2) b[j] = xf_apply8<T>(b[j], xf, col);
+                if constexpr (XF == 2) b[j] = xf_apply8_core<T>(b[j], csc, cmu, cbb);
             }
         }
 #pragma unroll
@@ -941,7 +959,7 @@ __global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restric
                 a[rb][j] = make_uint4(0, 0, 0, 0);
                 if (rs[rb] && px + 8 * j < HW) {
                     a[rb][j] = *reinterpret_cast<const uint4*>(rp + 8 * j);
-                    if constexpr (XF == 1) a[rb][j] = xf_apply8<T>(a[rb][j], xf, row0 + 32 * rb + c);
+                    if constexpr (XF == 1) a[rb][j] = xf_apply8_core<T>(a[rb][j], xsc[rb], xmu[rb], xb[rb]);
                 }
             }
         }
