@@ -433,8 +433,83 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restri
     const T* xn = x + (long long)n * wv.K * HW;
     T* yn = y + ((long long)n * wv.M + m_base) * HW;
 
-    stage_x_tile<T, 4, ALIGNED, XF>(Xs, xn, wv.K, HW, 0, p0, xf);
-    stage_w_tile<T, FO_ROWS, WVEC>(Ws, wv, m_base, 0);
+    if constexpr (Elem<T>::is16 && ALIGNED && WVEC) {
+        // one latency phase: the 8 weight loads (L2) and the 4 X loads (HBM) of a thread are all requested before either
+        // tile is written to LDS (staging X and then W costs an HBM round trip plus an L2 round trip)
+        const int tid = threadIdx.x;
+        const bool rowmajor = wv.sk == 1;
+        float4 wr[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int q = tid + it * PW_THREADS;
+            wr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rowmajor) {
+                const int r = q >> 4, kk = 4 * (q & 15);
+                if (r < mloc) {
+                    const float* src = wv.w + (long long)(m_base + r) * wv.sm + kk;
+                    if (kk + 3 < wv.K) wr[it] = *reinterpret_cast<const float4*>(src);
+                    else {
+                        if (kk < wv.K) wr[it].x = src[0];
+                        if (kk + 1 < wv.K) wr[it].y = src[1];
+                        if (kk + 2 < wv.K) wr[it].z = src[2];
+                    }
+                }
+            } else {
+                const int k = q >> 5, r = 4 * (q & 31);
+                const int m = m_base + r;
+                if (k < wv.K) {
+                    const float* src = wv.w + (long long)k * wv.sk + m;
+                    if (m + 3 < wv.M) wr[it] = *reinterpret_cast<const float4*>(src);
+                    else {
+                        if (m < wv.M) wr[it].x = src[0];
+                        if (m + 1 < wv.M) wr[it].y = src[1];
+                        if (m + 2 < wv.M) wr[it].z = src[2];
+                    }
+                }
+            }
+        }
+        uint4 xr[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int q = tid + it * PW_THREADS;
+            const int k = q >> 4, px = p0 + 8 * (q & 15);
+            xr[it] = make_uint4(0, 0, 0, 0);
+            if (k < wv.K && px < HW) xr[it] = *reinterpret_cast<const uint4*>(xn + (long long)k * HW + px);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int q = tid + it * PW_THREADS;
+            if (rowmajor) {
+                const int r = q >> 4, k = 4 * (q & 15);
+                *reinterpret_cast<uint2*>(Ws + wtile_off<T>(r, k)) =
+                    make_uint2(pack2<T>(wr[it].x, wr[it].y), pack2<T>(wr[it].z, wr[it].w));
+            } else {
+                const int k = q >> 5, r = 4 * (q & 31);
+                lds_store_w<T>(Ws, wtile_off<T>(r, k), wr[it].x);
+                lds_store_w<T>(Ws, wtile_off<T>(r + 1, k), wr[it].y);
+                lds_store_w<T>(Ws, wtile_off<T>(r + 2, k), wr[it].z);
+                lds_store_w<T>(Ws, wtile_off<T>(r + 3, k), wr[it].w);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int q = tid + it * PW_THREADS;
+            const int k = q >> 4, m = q & 15;
+            uint4 v = xr[it];
+            if constexpr (XF) {
+                if (k < wv.K && p0 + 8 * m < HW) v = xf_apply8<T>(v, xf, k);
+            }
+            // pixel 8m+i -> position 32*(i&3) + 2m + (i>>2): pairs (i, i+4) are adjacent   (stage_x_tile, PX = 4)
+            uint32_t* r32 = reinterpret_cast<uint32_t*>(Xs + k * XROW16);
+            r32[(32 * 0 + 2 * m) >> 1] = (v.x & 0xffffu) | (v.z << 16);
+            r32[(32 * 1 + 2 * m) >> 1] = (v.x >> 16) | (v.z & 0xffff0000u);
+            r32[(32 * 2 + 2 * m) >> 1] = (v.y & 0xffffu) | (v.w << 16);
+            r32[(32 * 3 + 2 * m) >> 1] = (v.y >> 16) | (v.w & 0xffff0000u);
+        }
+    } else {
+        stage_x_tile<T, 4, ALIGNED, XF>(Xs, xn, wv.K, HW, 0, p0, xf);
+        stage_w_tile<T, FO_ROWS, WVEC>(Ws, wv, m_base, 0);
+    }
     __syncthreads();
 
     const int cb = wave;
