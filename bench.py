@@ -145,7 +145,7 @@ def main():
     # ---- roofline of the dominant HIP kernel: events on the launch stream around every library launch
     roofline = None
     kernel_table = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:   # every rank runs the instrumented steps (they contain the gradient all-reduce); rank 0 reports
         # per-kernel timing needs one API call per kernel: the instrumented steps run the per-op Functions
         # (same kernels, same order) instead of the composite MB-block call used in the timed region
         ops.FUSED_BLOCK = False
