@@ -54,3 +54,29 @@ def test_step_is_bit_reproducible_and_stream_schedule_invariant():
     c = _run({"OFASR_MBCONV_SIDE_STREAM": "0"})
     assert a == b, "two identical runs differ: the path is not deterministic"
     assert a == c, "the side-stream schedule changed results"
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line with the driver's contract keys plus `roofline` and `cpu_baseline` (a short run)."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--cpu-steps", "1", "--cpu-images", "1"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["metric"] == "sr_training_images_per_sec_4x_64to256" and j["unit"] == "images/s"
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["dtype"] == "bf16" and j["data"] == "synthetic" and j["vs_baseline"] is None and j["higher_is_better"] is True
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and j["value"] > 100 * c["value"]
