@@ -67,3 +67,32 @@ def test_conv_layer_uses_hip_conv_under_autocast():
         outs.append(y.float())
     assert outs[0].shape == (2, 64, 16, 128)
     assert float((outs[0] - outs[1]).detach().abs().max()) < 0.08
+
+
+@pytest.mark.parametrize("shape", [(16, 64, 256, 128, 128, 5), (16, 64, 3, 256, 256, 5), (16, 3, 64, 64, 64, 5)])
+def test_conv2d_full_size_properties(shape):
+    """BASELINE-size layers (the two up-sampler convs' big sibling, the head, the stem): size-independent checks.
+    (1) a one-hot kernel (centre tap, output channel m reads input channel m % Cin) makes the convolution a channel
+    selection -- exact in 16 bits, pins the pixel <-> MFMA-column permutation and the window addressing at full size;
+    (2) adjoint identities <dy, conv(x; w)> = <dgrad(dy; w), x> = <wgrad(dy, x), w> tie the three kernels together."""
+    ops = amd("ops")
+    N, Cin, Cout, H, W, K = shape
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = (torch.randint(-8, 9, (N, Cin, H, W), generator=g).float() / 8).to(torch.bfloat16).to(DEV)
+    w = torch.zeros(Cout, Cin, K, K, device=DEV)
+    for m in range(Cout):
+        w[m, m % Cin, K // 2, K // 2] = 1.0
+    y = ops.Conv2dFn.apply(x, w)
+    assert torch.equal(y, x[:, [m % Cin for m in range(Cout)]])
+    # adjoint identities with small-integer data (every product and partial sum exact in fp32 up to the final sums)
+    w2 = (torch.randint(-2, 3, (Cout, Cin, K, K), generator=g).float() / 4).to(DEV).requires_grad_(True)
+    xs = x[:2].clone().requires_grad_(True)
+    dy = (torch.randint(-4, 5, (2, Cout, H, W), generator=g).float() / 4).to(torch.bfloat16).to(DEV)
+    y2 = ops.Conv2dFn.apply(xs, w2)
+    y2.backward(dy)
+    lhs = float((dy.double() * y2.detach().double()).sum())
+    mid = float((xs.grad.double() * xs.detach().double()).sum())
+    rhs = float((w2.grad.double() * w2.detach().double()).sum())
+    scale = float((dy.double().abs() * y2.detach().double().abs()).sum()) + 1e-9
+    # y2 and dx are rounded to bf16 on store (relative 2^-9 per element, random sign): the sums agree far tighter
+    assert abs(lhs - mid) <= 2e-3 * scale and abs(lhs - rhs) <= 2e-3 * scale and abs(mid - rhs) <= 2e-3 * scale
