@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--h2d", action="store_true", help="copy the batch from pinned host memory inside every timed step "
+                                                       "(the PCIe-inclusive rate quoted in DESIGN.md; never `value`)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                                                       "the N>1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-images", type=int, default=2)
@@ -99,9 +101,13 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     hr = torch.rand((N, 3, 4 * S, 4 * S), generator=g)
     lr = F.interpolate(hr, scale_factor=0.25, mode="bicubic", antialias=True).clamp_(0, 1)
+    hr_host, lr_host = (hr.pin_memory(), lr.pin_memory()) if args.h2d else (None, None)
     hr, lr = hr.to(dev), lr.to(dev)
 
     def train_step(step):
+        if args.h2d:   # what the reference's loader hands over: host tensors
+            hr.copy_(hr_host, non_blocking=True)
+            lr.copy_(lr_host, non_blocking=True)
         if reducer is not None:
             reducer.prepare()
         else:
