@@ -294,6 +294,235 @@ __device__ __forceinline__ void build_window(const float* v, float* win, int lan
     for (int i = 0; i < PXL; ++i) win[PAD + i] = v[i];
 }
 
+// =================================================================================================
+// MFMA path for K >= 5 on 16-bit planes of width 32 / 64 and height <= 64 (the MB stack's shapes).
+// The vector kernel above is VALU-issue-bound there (4513 VALU instructions per wave against 1568 ideal packed FMAs:
+// every SGPR tap costs a v_mov per two packed FMAs).  Here one kernel row is a GEMM on the matrix cores:
+//     Out[h][w] = sum_ky  In_ky[h][j] * T_ky[j][w],   In_ky[h][j] = in[h + ky - P][j],  T_ky[j][w] = f[ky][j - w + P]
+// A (32 rows h x 16 columns j) is one ds_read_b128 of the plane image in LDS (rows shifted by ky, 8-aligned column
+// chunks, zero halo rows); B is the Toeplitz band of the taps, which only depends on (ky, j-chunk): 3*K fragments per
+// channel, built once per wave from a zero-padded tap table.  11x the flops of the direct form, on units 16x faster:
+// 12*K MFMAs per 64x64 plane.  The taps are rounded to the activation type (what autocast does to a conv weight).
+// wave = (channel, group of NPW images); no block-level barrier (each wave owns its LDS plane).
+// =================================================================================================
+typedef __attribute__((ext_vector_type(16))) float dwm_f32x16;
+typedef __attribute__((ext_vector_type(8))) short dwm_s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 dwm_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 dwm_f16x8;
+template <typename T> struct DwMma;
+template <> struct DwMma<bf16_t> {
+    static __device__ __forceinline__ dwm_f32x16 run(dwm_s16x8 a, dwm_s16x8 b, dwm_f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dwm_bf16x8, a), __builtin_bit_cast(dwm_bf16x8, b),
+                                                       c, 0, 0, 0);
+    }
+};
+template <> struct DwMma<f16_t> {
+    static __device__ __forceinline__ dwm_f32x16 run(dwm_s16x8 a, dwm_s16x8 b, dwm_f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dwm_f16x8, a), __builtin_bit_cast(dwm_f16x8, b), c,
+                                                      0, 0, 0);
+    }
+};
+constexpr int DWM_NPW = 4;   // images per wave (the Toeplitz fragments are built once per wave)
+// LDS accesses of one wave execute in issue order; this only keeps the COMPILER from moving differently-typed LDS
+// accesses across the point (and drains the LDS queue), which is all a wave-private buffer needs
+__device__ __forceinline__ void dwm_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <typename T, int K, bool FLIP, bool XF, bool STAT>
+__global__ void __launch_bounds__(64 * DW_WAVES) dw_mfma_kernel(const T* __restrict__ x, const float* __restrict__ f,
+                                                                T* __restrict__ y, int N, int C, int H, int W,
+                                                                int nslabs, InputXf xf, StatOut so, BnFold fold) {
+    constexpr int PAD = K / 2;
+    constexpr int LROWS = 64 + 2 * PAD;
+    __shared__ __attribute__((aligned(16))) char planes[DW_WAVES][LROWS * 128];
+    __shared__ __attribute__((aligned(16))) char outs[DW_WAVES][64 * 128];   // output image, written back in 16-byte rows
+    __shared__ uint16_t tapt[DW_WAVES][K][96];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long unit = (long long)blockIdx.x * DW_WAVES + wave;
+    const int c = (int)(unit % C);
+    const int n0 = (int)(unit / C) * DWM_NPW;
+    if (n0 >= N) return;   // wave-uniform; the kernel has no block barrier
+    char* L = planes[wave];
+    const int r = lane & 31, hh = lane >> 5;
+
+    // zero the plane image once (the halo rows stay zero) and build the zero-padded tap rows
+    for (int i = lane; i < LROWS * 8; i += 64) *reinterpret_cast<uint4*>(L + i * 16) = make_uint4(0, 0, 0, 0);
+    for (int i = lane; i < K * 96; i += 64) tapt[wave][i / 96][i % 96] = 0;
+    dwm_lds_fence();
+    for (int e = lane; e < K * K; e += 64)
+        tapt[wave][e / K][e % K + 40] = from_float<T>(f[(long long)c * K * K + (FLIP ? (K * K - 1 - e) : e)]).v;
+    dwm_lds_fence();
+    // Toeplitz fragments: lane (column n = r, half hh) holds T[j = d + 8hh + i][w = n] = tap[ky][d + 8hh + i - n + PAD]
+    dwm_s16x8 Bf[K][3];
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const int base = (-8 + 16 * ch) + 8 * hh - r + PAD + 40;
+            dwm_s16x8 b;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) b[i] = (short)tapt[wave][ky][base + i];
+            Bf[ky][ch] = b;
+        }
+
+    float xsc = 1.f, xmu = 0.f, xb = 0.f;   // fused BN + ReLU6 of the input plane (wave-uniform)
+    if constexpr (XF) {
+        if (fold.cp) {
+            double s = 0.0, ss = 0.0;
+            for (int q = lane; q < fold.P; q += 64) {
+                const float2 v = fold.cp[(long long)c * fold.P + q];
+                s += (double)v.x;
+                ss += (double)v.y;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                s += __shfl_xor(s, o, 64);
+                ss += __shfl_xor(ss, o, 64);
+            }
+            const double mean = s / fold.M;
+            double var = ss / fold.M - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double invstd = 1.0 / sqrt(var + fold.eps);
+            const double gm = fold.gamma ? (double)fold.gamma[c] : 1.0, bt = fold.beta ? (double)fold.beta[c] : 0.0;
+            xsc = (float)(gm * invstd);
+            xmu = (float)mean;
+            xb = (float)bt;
+            if (n0 == 0 && lane == 0) {   // image group 0's wave of channel c keeps the statistics
+                fold.mean[c] = (float)mean;
+                fold.invstd[c] = (float)invstd;
+                fold.scale[c] = xsc;
+                fold.shift[c] = (float)(bt - mean * gm * invstd);
+                if (fold.running_mean) {
+                    const double unb = fold.M > 1.0 ? var * fold.M / (fold.M - 1.0) : var;
+                    fold.running_mean[c] =
+                        (float)((1.0 - fold.momentum) * (double)fold.running_mean[c] + fold.momentum * mean);
+                    fold.running_var[c] = (float)((1.0 - fold.momentum) * (double)fold.running_var[c] + fold.momentum * unb);
+                }
+                if (c == 0) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        if (fold.counters[i]) *fold.counters[i] += 1;
+                }
+            }
+        } else {
+            xsc = xf.scale[c];
+            xmu = xf.mean[c];
+            xb = fmaf(xmu, xsc, xf.shift[c]);
+        }
+    }
+
+    const int cpr = W >> 3;                 // 16-byte chunks per image row (4 or 8)
+    const int nchunks = H * cpr;            // <= 512: at most 8 chunks per lane
+    char* O = outs[wave];
+    uint4 nxt[8];
+    auto load_plane = [&](int pl) {
+        const long long plane = (long long)(n0 + pl) * C + c;
+        const uint4* src = reinterpret_cast<const uint4*>(x + plane * (long long)H * W);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = lane + 64 * it;
+            nxt[it] = make_uint4(0, 0, 0, 0);
+            if (idx < nchunks) nxt[it] = src[idx];
+        }
+    };
+    load_plane(0);
+    for (int pl = 0; pl < DWM_NPW && n0 + pl < N; ++pl) {
+        const long long plane = (long long)(n0 + pl) * C + c;
+        // ---- the plane image: (fused BN + ReLU6), swizzled LDS rows; the next plane's loads go out right after
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = lane + 64 * it;
+            if (idx < nchunks) {
+                uint4 v = nxt[it];
+                if constexpr (XF) {
+                    uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        T lo, hi;
+                        lo.v = (uint16_t)(wv[i] & 0xffffu);
+                        hi.v = (uint16_t)(wv[i] >> 16);
+                        const float a = fminf(fmaxf(fmaf(to_float(lo) - xmu, xsc, xb), 0.f), 6.f);
+                        const float b = fminf(fmaxf(fmaf(to_float(hi) - xmu, xsc, xb), 0.f), 6.f);
+                        wv[i] = pack2<T>(a, b);
+                    }
+                    v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                }
+                const int row = idx / cpr, chunk = idx - row * cpr, lr = row + PAD;
+                *reinterpret_cast<uint4*>(L + lr * 128 + ((chunk ^ ((lr >> 1) & 7)) << 4)) = v;
+            }
+        }
+        dwm_lds_fence();   // the image is complete before any fragment is read
+        if (pl + 1 < DWM_NPW && n0 + pl + 1 < N) load_plane(pl + 1);
+        float st_s = 0.f, st_q = 0.f;
+        for (int hb = 0; hb < H / 32; ++hb) {
+            for (int wb = 0; wb < W / 32; ++wb) {
+                dwm_f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                    const int lr = 32 * hb + r + ky;   // LDS row of image row (32hb + r + ky - PAD)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const int cidx = 4 * wb - 1 + 2 * ch + hh;   // 8-column chunk of input columns 32wb - 8 + 16ch + 8hh
+                        dwm_s16x8 a;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) a[i] = 0;
+                        if (cidx >= 0 && cidx < cpr)
+                            a = *reinterpret_cast<const dwm_s16x8*>(L + lr * 128 + ((cidx ^ ((lr >> 1) & 7)) << 4));
+                        // transposed product: rows = output columns w (the Toeplitz operand), columns = image rows h
+                        acc = DwMma<T>::run(Bf[ky][ch], a, acc);
+                    }
+                }
+                // lane = image row h = 32hb + r; register group q holds columns w = 32wb + 8q + 4hh + (0..3): 8 bytes
+                const int h = 32 * hb + r;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint2 o = make_uint2(pack2<T>(acc[4 * q], acc[4 * q + 1]), pack2<T>(acc[4 * q + 2], acc[4 * q + 3]));
+                    const int chunk = 4 * wb + q;
+                    *reinterpret_cast<uint2*>(O + h * 128 + ((chunk ^ ((h >> 1) & 7)) << 4) + 8 * hh) = o;
+                    if constexpr (STAT) {
+                        const uint32_t wv2[2] = {o.x, o.y};
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            T lo, hi;
+                            lo.v = (uint16_t)(wv2[i] & 0xffffu);
+                            hi.v = (uint16_t)(wv2[i] >> 16);
+                            const float a0 = to_float(lo), a1 = to_float(hi);
+                            st_s += a0 + a1;
+                            st_q = fmaf(a0, a0, fmaf(a1, a1, st_q));
+                        }
+                    }
+                }
+            }
+        }
+        dwm_lds_fence();   // output image complete; every input fragment of this plane has been read
+        uint4* dst = reinterpret_cast<uint4*>(y + plane * (long long)H * W);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = lane + 64 * it;
+            if (idx < nchunks) {
+                const int row = idx / cpr, chunk = idx - row * cpr;
+                dst[idx] = *reinterpret_cast<const uint4*>(O + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+        }
+        dwm_lds_fence();   // the output image is read back before the next plane writes it
+        if constexpr (STAT) {
+            const float s = wave_sum(st_s), q = wave_sum(st_q);
+            if (lane == 0) {
+                so.partial[(long long)c * so.P + (long long)(n0 + pl) * nslabs] = make_float2(s, q);
+                for (int sl = 1; sl < nslabs; ++sl)
+                    so.partial[(long long)c * so.P + (long long)(n0 + pl) * nslabs + sl] = make_float2(0.f, 0.f);
+            }
+        }
+    }
+}
+
+static bool mfma_geom_ok(int64_t H, int64_t W, int K, const void* a, const void* b) {
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b);
+    return K >= 7 && (W == 32 || W == 64) && H >= 32 && H <= 64 && (H % 32) == 0 && (bits & 15) == 0;
+}
+
 struct VecGeom {
     int G, gpw, R, nslabs;   // lanes per row, groups per wave, rows per group, slabs per plane
 };
@@ -583,6 +812,26 @@ template <typename T, bool FLIP, bool XF = false, bool STAT = false>
 static int launch_conv(const char* name, const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H,
                        int64_t W, int K, hipStream_t st, InputXf xf = InputXf{}, StatOut so = StatOut{nullptr, 0},
                        BnFold fold = BnFold{}) {
+    if constexpr (sizeof(T) == 2) {
+        if (mfma_geom_ok(H, W, K, x, y)) {
+            VecGeom vg0;
+            const int nslabs = vec_geom(H, W, 2, 4, x, y, vg0) ? vg0.nslabs : 1;   // statistics slot layout of the vector path
+            if (STAT && so.P != (int)(N * nslabs)) {
+                set_error("%s: statistics slab count %d != %lld", name, so.P, (long long)(N * nslabs));
+                return OFASR_ERR_INVALID_ARG;
+            }
+            const long long units = (long long)C * cdiv(N, DWM_NPW);
+            if (K == 5)
+                hipLaunchKernelGGL((dw_mfma_kernel<T, 5, FLIP, XF, STAT>), dim3((unsigned)cdiv(units, DW_WAVES)),
+                                   dim3(64 * DW_WAVES), 0, st, (const T*)x, f, (T*)y, (int)N, (int)C, (int)H, (int)W, nslabs,
+                                   xf, so, fold);
+            else
+                hipLaunchKernelGGL((dw_mfma_kernel<T, 7, FLIP, XF, STAT>), dim3((unsigned)cdiv(units, DW_WAVES)),
+                                   dim3(64 * DW_WAVES), 0, st, (const T*)x, f, (T*)y, (int)N, (int)C, (int)H, (int)W, nslabs,
+                                   xf, so, fold);
+            return check_launch(name);
+        }
+    }
     {
         VecGeom vg;
 #define OFASR_DWV(KK)                                                                                               \

@@ -227,6 +227,27 @@ def test_dwconv_full_size_linearity(ops):
     assert float(y[:, :, :3].abs().max()) == 0 and float(y[:, :, :, 61:].abs().max()) == 0
 
 
+def test_dwconv_full_size_16bit_matrix_core_path(ops):
+    """BASELINE size [16,384,64,64], k=7, bf16: the depthwise conv runs as Toeplitz GEMMs on the matrix cores; delta
+    filters make it an exact identity / shift (pins the swizzled plane image, the band fragments and the transposed
+    write-back at full size), forward and input gradient."""
+    torch.manual_seed(1)
+    x = torch.randn(16, 384, 64, 64, device=DEV).to(torch.bfloat16)
+    d = torch.zeros(384, 1, 7, 7, device=DEV)
+    d[:, 0, 3, 3] = 1.0
+    assert torch.equal(ops.dwconv(x, d), x)
+    d.zero_()
+    d[:, 0, 1, 5] = 1.0          # y[h, w] = x[h - 2, w + 2]
+    xr = x.clone().requires_grad_(True)
+    y = ops.dwconv(xr, d)
+    assert torch.equal(y[:, :, 2:, :62], x[:, :, :62, 2:])
+    assert float(y[:, :, :2].abs().max()) == 0 and float(y[:, :, :, 62:].abs().max()) == 0
+    g = torch.randn_like(y)
+    y.backward(g)                # dx[h, w] = g[h + 2, w - 2]
+    assert torch.equal(xr.grad[:, :, :62, 2:], g[:, :, 2:, :62])
+    assert float(xr.grad[:, :, 62:].abs().max()) == 0 and float(xr.grad[:, :, :, :2].abs().max()) == 0
+
+
 # -------------------------------------------------------------------------------- pointwise
 PW_CASES = [
     # (N, Cin, Cout_active, Cin_max, Cout_max, H, W)
