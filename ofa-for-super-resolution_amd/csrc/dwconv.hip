@@ -323,6 +323,7 @@ template <> struct DwMma<f16_t> {
     }
 };
 constexpr int DWM_NPW = 4;   // images per wave (the Toeplitz fragments are built once per wave)
+constexpr int DWM_PITCH = 144;
 // LDS accesses of one wave execute in issue order; this only keeps the COMPILER from moving differently-typed LDS
 // accesses across the point (and drains the LDS queue), which is all a wave-private buffer needs
 __device__ __forceinline__ void dwm_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -333,7 +334,10 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_mfma_kernel(const T* __restr
                                                                 int nslabs, InputXf xf, StatOut so, BnFold fold) {
     constexpr int PAD = K / 2;
     constexpr int LROWS = 64 + 2 * PAD;
-    __shared__ __attribute__((aligned(16))) char planes[DW_WAVES][LROWS * 128];
+    // plane image rows of DWM_PITCH bytes: 8 data chunks of 16 B + ONE zero chunk (index 8) that serves as the left pad
+    // (chunk -1) and the right pad (chunk 8) of every row; 144 = 16 * 9 (odd) makes the b128 reads of 16 consecutive rows
+    // conflict-free without a swizzle, so every fragment address is a lane constant + an immediate
+    __shared__ __attribute__((aligned(16))) char planes[DW_WAVES][LROWS * DWM_PITCH];
     __shared__ __attribute__((aligned(16))) char outs[DW_WAVES][64 * 128];   // output image, written back in 16-byte rows
     __shared__ uint16_t tapt[DW_WAVES][K][96];
     const int lane = lane_id();
@@ -346,7 +350,7 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_mfma_kernel(const T* __restr
     const int r = lane & 31, hh = lane >> 5;
 
     // zero the plane image once (the halo rows stay zero) and build the zero-padded tap rows
-    for (int i = lane; i < LROWS * 8; i += 64) *reinterpret_cast<uint4*>(L + i * 16) = make_uint4(0, 0, 0, 0);
+    for (int i = lane; i < LROWS * (DWM_PITCH / 16); i += 64) *reinterpret_cast<uint4*>(L + i * 16) = make_uint4(0, 0, 0, 0);
     for (int i = lane; i < K * 96; i += 64) tapt[wave][i / 96][i % 96] = 0;
     dwm_lds_fence();
     for (int e = lane; e < K * K; e += 64)
@@ -411,6 +415,15 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_mfma_kernel(const T* __restr
         }
     }
 
+    int abase[2][3];   // byte offset of this lane's fragment chunk for (column block, chunk pair), row r
+#pragma unroll
+    for (int wb = 0; wb < 2; ++wb)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const int cidx = 4 * wb - 1 + 2 * ch + hh;
+            const int cz = (cidx < 0 || cidx >= (W >> 3)) ? 8 : cidx;
+            abase[wb][ch] = r * DWM_PITCH + cz * 16;
+        }
     const int cpr = W >> 3;                 // 16-byte chunks per image row (4 or 8)
     const int nchunks = H * cpr;            // <= 512: at most 8 chunks per lane
     char* O = outs[wave];
@@ -448,28 +461,28 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_mfma_kernel(const T* __restr
                     v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
                 }
                 const int row = idx / cpr, chunk = idx - row * cpr, lr = row + PAD;
-                *reinterpret_cast<uint4*>(L + lr * 128 + ((chunk ^ ((lr >> 1) & 7)) << 4)) = v;
+                *reinterpret_cast<uint4*>(L + lr * DWM_PITCH + (chunk << 4)) = v;
             }
         }
         dwm_lds_fence();   // the image is complete before any fragment is read
         if (pl + 1 < DWM_NPW && n0 + pl + 1 < N) load_plane(pl + 1);
         float st_s = 0.f, st_q = 0.f;
         for (int hb = 0; hb < H / 32; ++hb) {
-            for (int wb = 0; wb < W / 32; ++wb) {
+            const char* Lh = L + hb * (32 * DWM_PITCH);
+#pragma unroll
+            for (int wb = 0; wb < 2; ++wb) {
+                if (32 * wb >= W) break;   // wave-uniform; unrolled so that abase[wb][ch] is a register, not an indexed array
                 dwm_f32x16 acc;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
                 for (int ky = 0; ky < K; ++ky) {
-                    const int lr = 32 * hb + r + ky;   // LDS row of image row (32hb + r + ky - PAD)
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
-                        const int cidx = 4 * wb - 1 + 2 * ch + hh;   // 8-column chunk of input columns 32wb - 8 + 16ch + 8hh
-                        dwm_s16x8 a;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) a[i] = 0;
-                        if (cidx >= 0 && cidx < cpr)
-                            a = *reinterpret_cast<const dwm_s16x8*>(L + lr * 128 + ((cidx ^ ((lr >> 1) & 7)) << 4));
+                        // input columns 32wb - 8 + 16ch + 8hh: chunk 4wb - 1 + 2ch + hh, -1 and 8 -> the zero chunk;
+                        // image row 32hb + r + ky - PAD is LDS row 32hb + r + ky: lane base + immediate
+                        const dwm_s16x8 a =
+                            *reinterpret_cast<const dwm_s16x8*>(Lh + abase[wb][ch] + ky * DWM_PITCH);
                         // transposed product: rows = output columns w (the Toeplitz operand), columns = image rows h
                         acc = DwMma<T>::run(Bf[ky][ch], a, acc);
                     }
