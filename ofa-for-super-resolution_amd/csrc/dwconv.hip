@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_mfma_kernel(const T* __restr
 
 static bool mfma_geom_ok(int64_t H, int64_t W, int K, const void* a, const void* b) {
     const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b);
-    return K >= 7 && (W == 32 || W == 64) && H >= 32 && H <= 64 && (H % 32) == 0 && (bits & 15) == 0;
+    return K >= 5 && (W == 32 || W == 64) && H >= 32 && H <= 64 && (H % 32) == 0 && (bits & 15) == 0;
 }
 
 struct VecGeom {
