@@ -208,6 +208,17 @@ int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, void* act_buf, f
 int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, const void* act_buf, const float* stat_buf,
                      const void* dout, void* dx, void* tmp_buf, const ofasr_mbconv_grads* g, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* ofasr_mbconv_bwd runs the weight-gradient kernels on a library-owned side stream beside the input-gradient chain
+ * and, by default, ends by ordering them before whatever the caller enqueues next on `stream`.
+ * ofasr_mbconv_defer_join(1) (process-wide; returns the previous setting) drops that per-call join: on return dx,
+ * dgamma[] and dbeta[] are final in stream order, while dw1, dw2, dwdw_max and dmats[] are final only after
+ * ofasr_mbconv_join(stream).  Until that join the caller must keep every buffer passed to the deferred calls valid
+ * and must not read those four gradients; a later call whose tmp_buf / workspace overlaps an unjoined call's waits for
+ * it.  This mirrors how the reference's autograd consumes them (torch AccumulateGrad at the end of backward(), read by
+ * the optimizer step, progressive_shrinking.py:199-203).  Not for use inside hipGraph capture (the side stream must
+ * re-join before a capture ends).  ofasr_mbconv_join is a no-op when nothing is pending. */
+int ofasr_mbconv_defer_join(int enable);
+int ofasr_mbconv_join(void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense KxK convolution (K in {3,5}, stride 1, zero padding K/2, no bias) of the static ConvLayers as an

@@ -72,6 +72,8 @@ SIGNATURES = {
     "ofasr_mbconv_stat_floats": (_c_sz, [_c_vp]),
     "ofasr_mbconv_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "ofasr_mbconv_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "ofasr_mbconv_defer_join": (_c_int, [_c_int]),
+    "ofasr_mbconv_join": (_c_int, [_c_vp]),
 }
 
 

@@ -9,6 +9,8 @@
 // Python side makes 1 FFI call per direction instead of ~25 (each with its own autograd node, allocations
 // and ctypes marshalling), which is what bounded the training step once the kernels were fast.
 #include "ofasr_common.h"
+#include <mutex>
+#include <vector>
 
 namespace ofasr {
 
@@ -89,11 +91,27 @@ __global__ void bump_counters_kernel(int64_t* a, int64_t* b, int64_t* c) {
 // kernels of a block's backward are independent of the input-gradient chain, so they run beside it and fill the
 // load / drain phases in which a lone bandwidth-bound kernel leaves HBM idle.  Created on first use; legal inside
 // hipGraph capture (fork/join through events).  OFASR_MBCONV_SIDE_STREAM=0 keeps everything on the caller's stream.
+//
+// Deferred join (ofasr_mbconv_defer_join(1)): by default a backward call ends by making the caller's stream wait for
+// the side stream, so every gradient is final in stream order when the call returns -- and the next block's
+// input-gradient chain queues behind this block's weight gradients (per block the cost is max(main, side), 7 % of the
+// north-star step).  With the join deferred the side stream runs free: the call returns with dx (and the BN gradients,
+// which the main chain writes) final in stream order, the weight / transform-matrix gradients only after
+// ofasr_mbconv_join(stream).  Until then the caller keeps every buffer of the call alive; a later call whose tmp_buf
+// or workspace overlaps those of an unjoined one waits for that one's side work first.
+struct PendingSide {
+    const char *t0, *t1, *w0, *w1;   // tmp_buf and workspace byte ranges the side kernels of the call still use
+    hipEvent_t done;                  // recorded on the side stream after the call's last side kernel
+};
+constexpr size_t MAX_PENDING = 64;
 struct SideStream {
-    bool ready = false, enabled = true;
+    bool ready = false, enabled = true, defer = false;
     hipStream_t s = nullptr;
     hipEvent_t fork[3] = {nullptr, nullptr, nullptr};
     hipEvent_t join = nullptr;
+    std::mutex mu;                    // guards pending / pool / defer
+    std::vector<PendingSide> pending;
+    std::vector<hipEvent_t> pool;     // done-events, created on demand, reused after a join
 };
 static SideStream& side_stream() {
     static SideStream ss;
@@ -109,6 +127,16 @@ static SideStream& side_stream() {
         }
     }
     return ss;
+}
+
+// `st` waits for everything enqueued on the side stream so far; clears the pending list (ss.mu held by the caller)
+static int join_side_locked(SideStream& ss, hipStream_t st, const char* name) {
+    if (!ss.enabled) return OFASR_OK;
+    hipError_t e = hipEventRecord(ss.join, ss.s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, ss.join, 0);
+    OFASR_REQUIRE(e == hipSuccess, OFASR_ERR_LAUNCH, "%s: stream join failed: %s", name, hipGetErrorString(e));
+    ss.pending.clear();
+    return OFASR_OK;
 }
 
 struct StatView {
@@ -351,6 +379,30 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
         hi = q.p + q.n > hi ? q.p + q.n : hi;
         sum += q.n;
     }
+    // unjoined side work of earlier calls that still reads the scratch this call is about to overwrite
+    SideStream& ss = side_stream();
+    const char* t_lo = (const char*)tmp_buf;
+    const char* t_hi = t_lo + (2 * s.mid_elems + (size_t)d->N * d->Cout * HW) * s.es;
+    const char* w_lo = (const char*)workspace;
+    const char* w_hi = w_lo + workspace_bytes;
+    bool defer = false;
+    {
+        std::lock_guard<std::mutex> lk(ss.mu);
+        defer = ss.enabled && ss.defer;
+        auto hits = [](const char* a0, const char* a1, const char* b0, const char* b1) { return a0 < b1 && b0 < a1; };
+        for (const PendingSide& p : ss.pending) {
+            if (hits(t_lo, t_hi, p.t0, p.t1) || hits(w_lo, w_hi, p.w0, p.w1) || hits(t_lo, t_hi, p.w0, p.w1) ||
+                hits(w_lo, w_hi, p.t0, p.t1)) {
+                hipError_t ew = hipStreamWaitEvent(st, p.done, 0);
+                OFASR_REQUIRE(ew == hipSuccess, OFASR_ERR_LAUNCH, "%s: wait for deferred side work failed: %s", name,
+                              hipGetErrorString(ew));
+            }
+        }
+        if (defer && ss.pending.size() >= MAX_PENDING) {   // bounded bookkeeping: fold everything into one join
+            rc = join_side_locked(ss, st, name);
+            if (rc) return rc;
+        }
+    }
     hipError_t e = hipSuccess;
     if ((size_t)(hi - lo) == sum) {   // disjoint spans (validated above) tiling [lo, hi) exactly
         e = hipMemsetAsync(lo, 0, sum, st);
@@ -365,7 +417,6 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
                           g->dbeta[2], d->N, d->Cout, HW, 0, d->bn_training[2], d->dtype, workspace, s.scratch, stream);
     if (rc) return rc;
     // From here the weight gradients go to the side stream: fork after the tensor they read is final, join at the end.
-    SideStream& ss = side_stream();
     const bool par = ss.enabled;
     void* sst = par ? (void*)ss.s : stream;   // stream of the weight-gradient kernels
     char* side_ws = (char*)workspace + s.scratch;
@@ -429,10 +480,44 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     else
         rc = ofasr_pwconv_dgrad(tB, d->w1, d->ldw1, dx, d->N, d->Cin, d->mid, HW, d->dtype, stream);
     if (rc) return rc;
-    if (par) {   // join: everything this call enqueued is ordered before whatever the caller enqueues next
-        hipError_t e2 = hipEventRecord(ss.join, ss.s);
-        if (e2 == hipSuccess) e2 = hipStreamWaitEvent(st, ss.join, 0);
-        OFASR_REQUIRE(e2 == hipSuccess, OFASR_ERR_LAUNCH, "%s: stream join failed: %s", name, hipGetErrorString(e2));
+    if (par) {
+        std::lock_guard<std::mutex> lk(ss.mu);
+        if (defer) {   // remember what the side kernels still use; ofasr_mbconv_join orders them before the caller
+            const size_t k = ss.pending.size();
+            if (ss.pool.size() <= k) {
+                hipEvent_t ev = nullptr;
+                const hipError_t e3 = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+                if (e3 != hipSuccess) {   // no event: fall back to the immediate join
+                    (void)hipGetLastError();
+                    return join_side_locked(ss, st, name);
+                }
+                ss.pool.push_back(ev);
+            }
+            const hipError_t e3 = hipEventRecord(ss.pool[k], ss.s);
+            OFASR_REQUIRE(e3 == hipSuccess, OFASR_ERR_LAUNCH, "%s: event record failed: %s", name, hipGetErrorString(e3));
+            ss.pending.push_back(PendingSide{t_lo, t_hi, w_lo, w_hi, ss.pool[k]});
+        } else {       // join: everything this call enqueued is ordered before whatever the caller enqueues next
+            rc = join_side_locked(ss, st, name);
+        }
     }
     return rc;
+}
+
+OFASR_EXPORT int ofasr_mbconv_defer_join(int enable) {
+    SideStream& ss = side_stream();
+    std::lock_guard<std::mutex> lk(ss.mu);
+    const int was = ss.defer ? 1 : 0;
+    if (!enable && ss.defer && !ss.pending.empty()) {   // leaving the mode with work in flight: drain it (blocking)
+        (void)hipStreamSynchronize(ss.s);
+        ss.pending.clear();
+    }
+    ss.defer = ss.enabled && enable != 0;
+    return was;
+}
+
+OFASR_EXPORT int ofasr_mbconv_join(void* stream) {
+    SideStream& ss = side_stream();
+    std::lock_guard<std::mutex> lk(ss.mu);
+    if (ss.pending.empty()) return OFASR_OK;
+    return join_side_locked(ss, as_stream(stream), "ofasr_mbconv_join");
 }

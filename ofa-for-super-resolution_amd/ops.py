@@ -390,6 +390,87 @@ def bn_act(x, bn, act=ACT_NONE, residual=None):
 FUSED_BLOCK = True   # DynamicMBConvLayer (+ shortcut) through ONE composite FFI call per direction
 
 
+# Deferred weight gradients of the composite block.  ofasr_mbconv_bwd computes the weight / transform-matrix gradients
+# on the library's side stream; joining that stream at the end of every block's backward makes the next block's
+# input-gradient chain queue behind them (7 % of the north-star step).  In deferred mode the backward node returns dx
+# and the BN gradients only, keeps the call's buffers alive, and a callback at the end of the backward pass
+# (torch's queue_callback, the hook DistributedDataParallel uses) joins the side stream once and then does what
+# AccumulateGrad would have done: p.grad = g or p.grad += g, followed by the parameter's post-accumulate hooks.
+# Visible differences: those .grad fields appear at the end of backward() instead of mid-way (a post-accumulate hook
+# runs once early, as for any parameter whose node receives no gradient, and again after the gradient is in place),
+# tensor hooks registered on the weights do not run, and torch.autograd.grad() does not return them -- use deferred_weight_grads(False) (or
+# OFASR_MBCONV_DEFER_JOIN=0) for such callers.  Only leaf parameters are deferred.
+DEFER_WGRAD = os.environ.get("OFASR_MBCONV_DEFER_JOIN", "1") != "0"
+
+
+class _Deferred(object):
+    queued = False      # a flush callback is installed for the running backward pass
+    lib_mode = None     # last value handed to ofasr_mbconv_defer_join
+    keep = []           # buffers the side stream may still be using
+    grads = []          # (parameter, gradient) pairs to accumulate after the join
+
+
+def deferred_weight_grads(enable=True):
+    """switch the deferred mode (see above); returns the previous setting."""
+    global DEFER_WGRAD
+    was, DEFER_WGRAD = DEFER_WGRAD, bool(enable)
+    return was
+
+
+def _set_lib_defer(on):
+    if _Deferred.lib_mode is not on:
+        _C.lib().ofasr_mbconv_defer_join(1 if on else 0)
+        _Deferred.lib_mode = on
+
+
+def _flush_deferred():
+    """join the library's side stream into the current stream, then accumulate the held weight gradients."""
+    _Deferred.queued = False
+    if not (_Deferred.keep or _Deferred.grads):
+        return
+    _C.check(_C.lib().ofasr_mbconv_join(_stream()), "mbconv_join")
+    grads, _Deferred.grads, _Deferred.keep = _Deferred.grads, [], []
+    with torch.no_grad():
+        for p, g in grads:
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+            hooks = getattr(p, "_post_accumulate_grad_hooks", None)
+            if hooks:
+                for h in list(hooks.values()):
+                    h(p)
+
+
+# scratch of the composite backward: a fresh tensor per call, or (SHARED_TMP) one cached buffer per size that every
+# block reuses -- the library orders a call behind unjoined side work that still reads the same bytes
+SHARED_TMP = os.environ.get("OFASR_MBCONV_SHARED_TMP", "0") != "0"
+_TMP_CACHE = {}
+
+
+def _bwd_scratch(numel, dtype, device):
+    if not SHARED_TMP:
+        return torch.empty(numel, dtype=dtype, device=device)
+    key = (numel, dtype, str(device))
+    t = _TMP_CACHE.get(key)
+    if t is None:
+        t = _TMP_CACHE[key] = torch.empty(numel, dtype=dtype, device=device)
+    return t
+
+
+def _defer_this_backward(params):
+    """True when this composite backward may leave its weight gradients to the end-of-pass callback."""
+    if not DEFER_WGRAD or not all(p.is_leaf for p in params):
+        return False
+    if not _Deferred.queued:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
+        except RuntimeError:      # not inside an engine-driven backward pass
+            return False
+        _Deferred.queued = True
+    return True
+
+
 class FusedMBConvFn(Function):
     """DynamicMBConvLayer.forward (+ identity shortcut) as ONE host call per direction (ofasr_mbconv_fwd/_bwd,
     include/ofasr.h): expand 1x1 -> BN+ReLU6 -> kernel transform -> depthwise -> BN+ReLU6 -> project 1x1 -> BN (+x).
@@ -401,6 +482,8 @@ class FusedMBConvFn(Function):
     @staticmethod
     def forward(ctx, x, cfg, w1, g1, b1, wdw, g2, b2, w2, g3, b3, *mats):
         _gpu(x, w1, wdw, w2)
+        if _Deferred.grads or _Deferred.keep:   # a backward pass that died before its callback: settle it now
+            _flush_deferred()
         x = x.contiguous()
         L = _C.lib()
         N, Cin, H, W = x.shape
@@ -456,7 +539,7 @@ class FusedMBConvFn(Function):
         HW = H * W
         dout = dout.contiguous()
         dx = torch.empty_like(x)
-        tmp = torch.empty(N * HW * (2 * d.mid + d.Cout), dtype=x.dtype, device=x.device)
+        tmp = _bwd_scratch(N * HW * (2 * d.mid + d.Cout), x.dtype, x.device)
         # the nine zero-initialised buffers first and adjacent: the library then clears them with one fill
         sizes = [w1.numel(), w2.numel(), wdw.numel()] + [g1.numel()] * 2 + [g2.numel()] * 2 + [g3.numel()] * 2 \
             + [m.numel() for m in mats]
@@ -471,9 +554,18 @@ class FusedMBConvFn(Function):
             g.dmats[i] = m.data_ptr()
         for i, (a, b) in enumerate(((dg1, db1), (dg2, db2), (dg3, db3))):
             g.dgamma[i], g.dbeta[i] = a.data_ptr(), b.data_ptr()
+        defer = _defer_this_backward((w1, wdw, w2) + tuple(mats))
+        _set_lib_defer(defer)
         with _timed("mbconv_bwd"):
             _C.check(L.ofasr_mbconv_bwd(ctypes.byref(d), _p(x), _p(act), _p(stat), _p(dout), _p(dx), _p(tmp),
                                         ctypes.byref(g), _p(ws), ws.numel(), _stream()), "mbconv_bwd")
+        if defer:
+            _Deferred.keep.append((x, act, stat, dout, tmp, ws, flat, bns, d, g, w1, wdw, w2, mats))
+            need = ctx.needs_input_grad
+            pairs = [(w1, dw1, need[2]), (wdw, dwdw, need[5]), (w2, dw2, need[8])] + \
+                [(m, dm, need[11 + i]) for i, (m, dm) in enumerate(zip(mats, dmats))]
+            _Deferred.grads.extend((p, gr) for p, gr, wanted in pairs if wanted)
+            return (dx, None, None, dg1, db1, None, dg2, db2, None, dg3, db3) + (None,) * len(dmats)
         return (dx, None, dw1, dg1, db1, dwdw, dg2, db2, dw2, dg3, db3) + tuple(dmats)
 
 

@@ -81,6 +81,52 @@ def test_bn_act_vs_oracle(ora, dtype, training, act, res, shape):
         assert_close(np.where(safe, rg.grad.float().cpu().numpy(), 0), np.where(safe, dz, 0), 1e-6, 1e-6, "dres")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("act", [0, 1])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("shape", [(16, 48, 64, 64), (5, 64, 64, 64), (16, 96, 32, 32), (3, 48, 96, 96)])
+def test_bn_bwd_large_shapes(dtype, act, training, shape):
+    """BASELINE-sized channel slices (16 x 64 x 64 per channel and ragged variants): dx, dgamma, dbeta of the 16-bit
+    backward against an fp64 restatement of the same formulas on the same 16-bit inputs."""
+    ops = amd("ops")
+    N, C, H, W = shape
+    bn, sd = _bn(C, prefix="bnres")
+    bn.to(DEV).train(training)
+    g = torch.Generator().manual_seed(1234 + N + C)
+    x = (torch.randn(shape, generator=g) * 1.5).to(dtype)
+    dy = torch.randn(shape, generator=g).to(dtype)
+    xg = x.to(DEV).requires_grad_(True)
+    rm0, rv0 = bn.running_mean.double().cpu().clone(), bn.running_var.double().cpu().clone()
+    y = ops.bn_act(xg, bn, act)
+    y.backward(dy.to(DEV))
+    xd, dyd = x.double(), dy.double()
+    if training:
+        mu = xd.mean(dim=(0, 2, 3), keepdim=True)
+        var = xd.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    else:
+        mu, var = rm0.view(1, C, 1, 1), rv0.view(1, C, 1, 1)
+    istd = 1.0 / torch.sqrt(var + 1e-5)
+    gam = bn.weight.detach().double().cpu().view(1, C, 1, 1)
+    bet = bn.bias.detach().double().cpu().view(1, C, 1, 1)
+    xhat = (xd - mu) * istd
+    pre = xhat * gam + bet
+    dz = dyd * ((pre > 0) & (pre < 6)) if act else dyd
+    db = dz.sum(dim=(0, 2, 3))
+    dg = (dz * xhat).sum(dim=(0, 2, 3))
+    M = N * H * W
+    dx = gam * istd * (dz - (db / M).view(1, C, 1, 1) - xhat * (dg / M).view(1, C, 1, 1)) if training else dz * gam * istd
+    safe = torch.ones_like(pre, dtype=torch.bool)
+    if act:
+        safe = (pre.abs() > 0.05) & ((pre - 6).abs() > 0.05)
+    rt, at = _tol(dtype)
+    got = xg.grad.double().cpu()
+    assert_close(torch.where(safe, got, 0.0).numpy(), torch.where(safe, dx, 0.0).numpy(), rt, at, "dx")
+    # the sums run over 1e4..1e5 terms of 16-bit data; a flipped mask bit at a window edge moves them by one term
+    scale = float(dz.abs().sum(dim=(0, 2, 3)).max())
+    assert float((bn.bias.grad.double().cpu() - db).abs().max()) <= 2e-4 * scale + 0.2 * act
+    assert float((bn.weight.grad.double().cpu() - dg).abs().max()) <= 2e-4 * scale * 3 + 0.6 * act
+
+
 def test_bn_golden_reference(golden):
     """the same goldens that pin the oracle (reference DynamicBatchNorm2d fwd/bwd, train and eval)."""
     dop = amd("elastic_nn.modules.dynamic_op")

@@ -1,0 +1,106 @@
+"""Deferred weight gradients of the composite MB block (ops.py `_Deferred`, include/ofasr.h ofasr_mbconv_defer_join /
+ofasr_mbconv_join): the weight-gradient kernels run on the library's side stream and are joined once at the end of the
+backward pass instead of once per block.  Results must be bit-identical to the immediate mode, including gradient
+accumulation over several backward passes (dynamic_batch_size > 1, reference progressive_shrinking.py:152-199),
+post-accumulate hooks (the data-parallel bucket relies on them) and a scratch buffer shared by all blocks."""
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import amd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _net():
+    dop = amd("elastic_nn.modules.dynamic_op")
+    nets = amd("elastic_nn.networks")
+    dop.DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = 1
+    torch.manual_seed(0)
+    return nets.OFAMobileNetS4(ks_list=[3, 5, 7], expand_ratio_list=[3, 4, 6], depth_list=[2, 3, 4],
+                               pixelshuffle_depth_list=[1, 2]).to(DEV).train()
+
+
+def _two_pass_grads(net, lr, hr, hooks=None):
+    net.zero_grad(set_to_none=True)
+    for sub in range(2):
+        random.seed(100 + sub)
+        net.sample_active_subnet()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = net(lr)
+        F.mse_loss(out.float(), hr).backward()
+    torch.cuda.synchronize()
+    return {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in net.named_parameters()}
+
+
+@pytest.mark.parametrize("shared_tmp", [False, True])
+def test_deferred_equals_immediate_with_accumulation(shared_tmp):
+    ops = amd("ops")
+    net = _net()
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    lr = torch.rand(4, 3, 32, 32, device=DEV)
+    hr = torch.rand(4, 3, 128, 128, device=DEV)
+    was, was_tmp = ops.deferred_weight_grads(False), ops.SHARED_TMP
+    try:
+        ref = _two_pass_grads(net, lr, hr)
+        net.load_state_dict(state)
+        ops.deferred_weight_grads(True)
+        ops.SHARED_TMP = shared_tmp
+        got = _two_pass_grads(net, lr, hr)
+        assert not ops._Deferred.keep and not ops._Deferred.grads and not ops._Deferred.queued
+    finally:
+        ops.deferred_weight_grads(was)
+        ops.SHARED_TMP = was_tmp
+    assert set(ref) == set(got)
+    n_def = 0
+    for n in ref:
+        assert (ref[n] is None) == (got[n] is None), "None-ness of %s.grad differs" % n
+        if ref[n] is not None:
+            assert torch.equal(ref[n], got[n]), n
+            n_def += 1
+    assert n_def > 50
+
+
+def test_deferred_runs_post_accumulate_hooks():
+    ops = amd("ops")
+    net = _net()
+    seen = []
+    w = net.blocks[0].mobile_inverted_conv.point_linear.conv.conv.weight
+    dw = net.blocks[0].mobile_inverted_conv.depth_conv.conv.conv.weight
+    hs = [w.register_post_accumulate_grad_hook(lambda p: seen.append(("pl", p.grad is not None))),
+          dw.register_post_accumulate_grad_hook(lambda p: seen.append(("dw", p.grad is not None)))]
+    was = ops.deferred_weight_grads(True)
+    try:
+        random.seed(3)
+        net.sample_active_subnet()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = net(torch.rand(2, 3, 32, 32, device=DEV))
+        out.float().square().mean().backward()
+    finally:
+        ops.deferred_weight_grads(was)
+        for h in hs:
+            h.remove()
+    # the engine also runs a parameter's hooks when its node receives no gradient (p.grad still None there); the flush
+    # runs them again once the gradient is in place
+    assert sorted(seen[-2:]) == [("dw", True), ("pl", True)]
+    assert w.grad is not None and dw.grad is not None
+
+
+def test_autograd_grad_falls_back_outside_accumulate_callers():
+    """with the mode off, torch.autograd.grad returns the composite's weight gradients as usual."""
+    ops = amd("ops")
+    net = _net()
+    w = net.blocks[0].mobile_inverted_conv.point_linear.conv.conv.weight
+    was = ops.deferred_weight_grads(False)
+    try:
+        random.seed(3)
+        net.sample_active_subnet()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = net(torch.rand(2, 3, 32, 32, device=DEV))
+        (gw,) = torch.autograd.grad(out.float().square().mean(), [w])
+    finally:
+        ops.deferred_weight_grads(was)
+    assert gw is not None and float(gw.abs().sum()) > 0 and w.grad is None

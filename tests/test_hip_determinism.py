@@ -52,8 +52,12 @@ def test_step_is_bit_reproducible_and_stream_schedule_invariant():
     a = _run({"OFASR_MBCONV_SIDE_STREAM": "1"})
     b = _run({"OFASR_MBCONV_SIDE_STREAM": "1"})
     c = _run({"OFASR_MBCONV_SIDE_STREAM": "0"})
+    d = _run({"OFASR_MBCONV_DEFER_JOIN": "0"})
+    e = _run({"OFASR_MBCONV_SHARED_TMP": "1"})
     assert a == b, "two identical runs differ: the path is not deterministic"
     assert a == c, "the side-stream schedule changed results"
+    assert a == d, "deferring the weight-gradient join to the end of backward changed results"
+    assert a == e, "one shared backward scratch buffer (ordered by the library's overlap waits) changed results"
 
 
 def test_bench_contract_line():
