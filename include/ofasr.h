@@ -219,6 +219,10 @@ int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, const void* act_
  * re-join before a capture ends).  ofasr_mbconv_join is a no-op when nothing is pending. */
 int ofasr_mbconv_defer_join(int enable);
 int ofasr_mbconv_join(void* stream);
+/* The library's side stream (a hipStream_t; NULL when OFASR_MBCONV_SIDE_STREAM=0), for callers that enqueue further
+ * independent work beside the composite calls -- the host mirror puts the static convs' weight gradients there.  Such
+ * work is ordered by the caller (events); ofasr_mbconv_join does not know about it. */
+void* ofasr_side_stream(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense KxK convolution (K in {3,5}, stride 1, zero padding K/2, no bias) of the static ConvLayers as an

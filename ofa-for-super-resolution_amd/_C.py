@@ -74,6 +74,7 @@ SIGNATURES = {
     "ofasr_mbconv_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "ofasr_mbconv_defer_join": (_c_int, [_c_int]),
     "ofasr_mbconv_join": (_c_int, [_c_vp]),
+    "ofasr_side_stream": (_c_vp, []),
 }
 
 

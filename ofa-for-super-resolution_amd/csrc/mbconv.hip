@@ -515,6 +515,13 @@ OFASR_EXPORT int ofasr_mbconv_defer_join(int enable) {
     return was;
 }
 
+// the side stream itself, for callers that put further independent work (e.g. the static convs' weight gradients)
+// beside the composite calls; NULL when OFASR_MBCONV_SIDE_STREAM=0.  Ordering such work is the caller's business.
+OFASR_EXPORT void* ofasr_side_stream(void) {
+    SideStream& ss = side_stream();
+    return ss.enabled ? (void*)ss.s : nullptr;
+}
+
 OFASR_EXPORT int ofasr_mbconv_join(void* stream) {
     SideStream& ss = side_stream();
     std::lock_guard<std::mutex> lk(ss.mu);

@@ -408,6 +408,17 @@ class _Deferred(object):
     lib_mode = None     # last value handed to ofasr_mbconv_defer_join
     keep = []           # buffers the side stream may still be using
     grads = []          # (parameter, gradient) pairs to accumulate after the join
+    ext = {}            # device index -> torch view of the library's side stream (None when it is disabled)
+    ext_used = set()    # devices whose side stream got work from this module since the last flush
+
+
+def _lib_side_stream(device):
+    """the library's side stream as a torch stream (so that torch events / `with torch.cuda.stream` work on it)."""
+    key = torch.device(device).index or 0
+    if key not in _Deferred.ext:
+        h = _C.lib().ofasr_side_stream()
+        _Deferred.ext[key] = torch.cuda.ExternalStream(h, device=device) if h else None
+    return _Deferred.ext[key]
 
 
 def deferred_weight_grads(enable=True):
@@ -429,6 +440,9 @@ def _flush_deferred():
     if not (_Deferred.keep or _Deferred.grads):
         return
     _C.check(_C.lib().ofasr_mbconv_join(_stream()), "mbconv_join")
+    for key in _Deferred.ext_used:      # work this module put on the side stream itself (static-conv weight gradients)
+        torch.cuda.current_stream(key).wait_stream(_Deferred.ext[key])
+    _Deferred.ext_used = set()
     grads, _Deferred.grads, _Deferred.keep = _Deferred.grads, [], []
     with torch.no_grad():
         for p, g in grads:
@@ -574,6 +588,12 @@ class FusedMBConvFn(Function):
 # slower on the north-star step (tools/ab_side.py) -- the two MFMA kernels each want every CU's LDS -- while the same
 # fork/join inside the composite MB-block backward (bandwidth-bound kernels, csrc/mbconv.hip) is 6 % faster.
 SIDE_STREAM = os.environ.get("OFASR_CONV_SIDE_STREAM", "0") != "0"
+# The static convs' weight gradients on the library's side stream, joined with the composite blocks' at the end of the
+# backward pass (needs DEFER_WGRAD).  Off by default: measured 2213 against 2262 images/s with all of them deferred and
+# no change with only the large-plane tail convs (OFASR_CONV_DEFER_MIN_HW) -- the main chain is the critical path
+# (tools/stream_balance.py) and the MFMA weight-gradient kernels slow its kernels down more than they save.
+CONV_DEFER_WGRAD = os.environ.get("OFASR_CONV_DEFER_WGRAD", "0") != "0"
+CONV_DEFER_MIN_HW = int(os.environ.get("OFASR_CONV_DEFER_MIN_HW", "0"))
 _SIDE_STREAMS = {}
 
 
@@ -635,6 +655,14 @@ class Conv2dFn(Function):
         # through its load / drain phases).  Buffers are allocated on the current stream; fork before, join after.
         cur = torch.cuda.current_stream(x.device)
         side = _side_stream(x.device) if (ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and SIDE_STREAM) else None
+        # deferred mode: the weight gradient goes to the library's side stream and is joined (with the composite
+        # blocks' weight gradients) once at the end of the backward pass -- it overlaps whatever backward runs next
+        defer = False
+        if ctx.needs_input_grad[1] and side is None and CONV_DEFER_WGRAD and H * W >= CONV_DEFER_MIN_HW \
+                and _lib_side_stream(x.device) is not None:
+            defer = _defer_this_backward((weight,))
+            if defer:
+                side = _lib_side_stream(x.device)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             wst2, wsp2, wsn2 = _ws(L.ofasr_conv2d_wgrad_workspace(N, Cin, Cout, H, W, K), x.device)
@@ -652,6 +680,11 @@ class Conv2dFn(Function):
                         2 * N * H * W * Cin * Cout * K * K):
                 _C.check(L.ofasr_conv2d_dgrad(_p(dy), _p(weight), _p(dx), N, Cin, Cout, H, W, K, _dt(x), wsp, wsn,
                                               _stream()), "conv2d_dgrad")
+        if defer:
+            _Deferred.keep.append((x, dy, dw, wst2, weight))
+            _Deferred.grads.append((weight, dw))
+            _Deferred.ext_used.add(torch.device(x.device).index or 0)
+            return dx, None, None
         if side is not None:
             cur.wait_stream(side)
         return dx, dw, None

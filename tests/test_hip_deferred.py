@@ -104,3 +104,24 @@ def test_autograd_grad_falls_back_outside_accumulate_callers():
     finally:
         ops.deferred_weight_grads(was)
     assert gw is not None and float(gw.abs().sum()) > 0 and w.grad is None
+
+
+def test_static_conv_weight_gradients_on_the_side_stream():
+    """the optional deferral of the static convs' weight gradients (ops.CONV_DEFER_WGRAD) gives identical gradients."""
+    ops = amd("ops")
+    net = _net()
+    lr = torch.rand(2, 3, 32, 32, device=DEV)
+    hr = torch.rand(2, 3, 128, 128, device=DEV)
+    was, was_conv = ops.deferred_weight_grads(True), ops.CONV_DEFER_WGRAD
+    try:
+        ops.CONV_DEFER_WGRAD = False
+        ref = _two_pass_grads(net, lr, hr)
+        ops.CONV_DEFER_WGRAD = True
+        got = _two_pass_grads(net, lr, hr)
+    finally:
+        ops.deferred_weight_grads(was)
+        ops.CONV_DEFER_WGRAD = was_conv
+    for n in ref:
+        assert (ref[n] is None) == (got[n] is None), n
+        if ref[n] is not None:
+            assert torch.equal(ref[n], got[n]), n
