@@ -556,6 +556,131 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restri
     if (so.partial) stat_epilogue<T, 4>(acc, p0 + 4 * c, HW, c, h, 32 * cb, mloc, m_base, so, tile);
 }
 
+
+// ------------------------------------------------------------------------------ fan-out, slab walk
+// Same tile maths as pw_fanout_kernel for the hot shape class (16-bit, aligned, vector weights, K == 64, M == NSLAB*128,
+// HW % 128 == 0): ONE block per 128-pixel tile walks the NSLAB 128-row output slabs.  The X tile is staged once (the
+// per-slab grid re-reads it from L2 for every slab) and the weight slab of round s+1 is requested before the MFMAs of
+// round s.  The kernel is store-dominated (a 64 -> 384 expand writes 6x what it reads), so what matters is that a wave
+// never waits for its own stores: vector-memory operations retire in order, so (a) the rounds are fully unrolled
+// straight-line code without a single divergent or wave-dependent branch -- then the compiler's s_waitcnt for the
+// prefetched weights is exact (vmcnt = the 16-17 younger stores) instead of vmcnt(0) -- and (b) the barriers order LDS
+// only (__syncthreads() would drain the stores too).
+// workgroup barrier that orders LDS traffic only
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename T>
+__device__ __forceinline__ void fo_load_w(float4 (&wr)[8], const WView& wv, bool rowmajor, int m_base, int tid) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int q = tid + it * PW_THREADS;
+        const long long off = rowmajor ? (long long)(m_base + (q >> 4)) * wv.sm + 4 * (q & 15)
+                                       : (long long)(q >> 5) * wv.sk + m_base + 4 * (q & 31);
+        wr[it] = *reinterpret_cast<const float4*>(wv.w + off);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void fo_store_w(char* Ws, const float4 (&wr)[8], bool rowmajor, int tid) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int q = tid + it * PW_THREADS;
+        if (rowmajor) {
+            const int r = q >> 4, k = 4 * (q & 15);
+            *reinterpret_cast<uint2*>(Ws + wtile_off<T>(r, k)) =
+                make_uint2(pack2<T>(wr[it].x, wr[it].y), pack2<T>(wr[it].z, wr[it].w));
+        } else {
+            const int k = q >> 5, r = 4 * (q & 31);
+            lds_store_w<T>(Ws, wtile_off<T>(r, k), wr[it].x);
+            lds_store_w<T>(Ws, wtile_off<T>(r + 1, k), wr[it].y);
+            lds_store_w<T>(Ws, wtile_off<T>(r + 2, k), wr[it].z);
+            lds_store_w<T>(Ws, wtile_off<T>(r + 3, k), wr[it].w);
+        }
+    }
+}
+
+template <typename T, int NSLAB, bool STAT>
+__global__ void __launch_bounds__(PW_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+pw_fanout_slabs_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y, int HW, int tiles_per_img, StatOut so) {
+    static_assert(Elem<T>::is16, "16-bit activations only");
+    __shared__ __attribute__((aligned(16))) char Ws[FO_ROWS * Elem<T>::wrow];
+    __shared__ __attribute__((aligned(16))) char Xs[64 * Elem<T>::xrow];
+    const int lane = lane_id();
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int c = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x;
+    const int n = tile / tiles_per_img;
+    const int p0 = (tile - n * tiles_per_img) * PW_TILE;
+    const T* xn = x + (long long)n * wv.K * HW;
+    const bool rowmajor = wv.sk == 1;
+    float4 wr[8];
+    fo_load_w<T>(wr, wv, rowmajor, 0, tid);
+    {
+        uint4 xr[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int q = tid + it * PW_THREADS;
+            xr[it] = *reinterpret_cast<const uint4*>(xn + (long long)(q >> 4) * HW + p0 + 8 * (q & 15));
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int q = tid + it * PW_THREADS;
+            const int k = q >> 4, m = q & 15;
+            const uint4 v = xr[it];
+            // pixel 8m+i -> position 32*(i&3) + 2m + (i>>2): pairs (i, i+4) are adjacent   (stage_x_tile, PX = 4)
+            uint32_t* r32 = reinterpret_cast<uint32_t*>(Xs + k * XROW16);
+            r32[(32 * 0 + 2 * m) >> 1] = (v.x & 0xffffu) | (v.z << 16);
+            r32[(32 * 1 + 2 * m) >> 1] = (v.x >> 16) | (v.z & 0xffff0000u);
+            r32[(32 * 2 + 2 * m) >> 1] = (v.y & 0xffffu) | (v.w << 16);
+            r32[(32 * 3 + 2 * m) >> 1] = (v.y >> 16) | (v.w & 0xffff0000u);
+        }
+    }
+    const int cb = wave;
+    const int row = 32 * cb + c;
+    const int px = p0 + 4 * c;
+#pragma unroll
+    for (int sl = 0; sl < NSLAB; ++sl) {
+        const int m_base = sl * FO_ROWS;
+        fo_store_w<T>(Ws, wr, rowmajor, tid);
+        lds_barrier();                                     // Ws (and, in round 0, Xs) visible
+        if (sl + 1 < NSLAB) fo_load_w<T>(wr, wv, rowmajor, m_base + FO_ROWS, tid);   // in flight over this round
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const s16x8 af = *reinterpret_cast<const s16x8*>(Ws + wtile_chunk_off<T>(row, 2 * s + h));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = Mma16<T>::run(af, read_b_frag16(Xs, 32 * t, s, lane), acc[t]);
+        }
+        T* yn = y + ((long long)n * wv.M + m_base + 32 * cb) * HW + px;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            *reinterpret_cast<uint2*>(yn + (long long)acc_row(reg, h) * HW) =
+                make_uint2(pack2<T>(acc[0][reg], acc[1][reg]), pack2<T>(acc[2][reg], acc[3][reg]));
+        if constexpr (STAT) {
+            float sv[16], qv[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                float ss = 0.f, qq = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float v = to_float(from_float<T>(acc[t][reg]));   // the values as stored
+                    ss += v;
+                    qq = fmaf(v, v, qq);
+                }
+                sv[reg] = ss;
+                qv[reg] = qq;
+            }
+            half_wave_row_sums(sv, qv, c);
+            // the two lanes of a b0 pair hold the same totals and store them to the same place (no lane-dependent branch)
+            const int r = m_base + 32 * cb + acc_row(half_wave_row_reg(c), h);
+            so.partial[(long long)r * so.P + tile] = make_float2(sv[0], qv[0]);
+        }
+        if (sl + 1 < NSLAB) lds_barrier();                 // every wave is done reading Ws
+    }
+}
+
 // ------------------------------------------------------------------------------------- fan-in
 // any K, 64 output rows per grid.y pass.  K is walked in 64-channel chunks: each chunk stages its X
 // tile (HBM) and its [64 x 64] weight chunk (L2) and adds into accumulators that stay in registers.
@@ -1102,6 +1227,22 @@ static void launch_gemm_v(const void* x, WView wv, void* y, int64_t HW, int tile
                           hipStream_t st, InputXf xf = InputXf{}, const void* addend = nullptr,
                           StatOut so = StatOut{nullptr, 0}, BnFold fold = BnFold{}) {
     if (wv.K <= 64) {
+        if constexpr (Elem<T>::is16 && AL && WV && !XF) {
+            // one block per pixel tile walking the row slabs (OFASR_PW_FANOUT_SLABS=0: per-slab grid)
+            static const bool slabs = [] { const char* e = getenv("OFASR_PW_FANOUT_SLABS"); return !(e && e[0] == '0'); }();
+            const int nslab = wv.M / FO_ROWS;
+            if (slabs && addend == nullptr && wv.K == 64 && wv.M % FO_ROWS == 0 && (nslab == 2 || nslab == 3) &&
+                HW % PW_TILE == 0) {
+                dim3 g1((unsigned)total_tiles);
+#define OFASR_FO_SLABS(NS, ST)                                                                                       \
+    hipLaunchKernelGGL((pw_fanout_slabs_kernel<T, NS, ST>), g1, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y, (int)HW, \
+                       tiles_per_img, so)
+                if (nslab == 3) { if (so.partial) OFASR_FO_SLABS(3, true); else OFASR_FO_SLABS(3, false); }
+                else { if (so.partial) OFASR_FO_SLABS(2, true); else OFASR_FO_SLABS(2, false); }
+#undef OFASR_FO_SLABS
+                return;
+            }
+        }
         dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, FO_ROWS));
         hipLaunchKernelGGL((pw_fanout_kernel<T, AL, WV, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
                            (int)HW, tiles_per_img, xf, (const T*)addend, so);
