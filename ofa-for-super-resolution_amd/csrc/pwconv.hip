@@ -762,7 +762,7 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_kernel(const T* __restric
 // barriers and the MFMAs of a round hide behind the next chunk's HBM round trip instead of adding to it (measured
 // timeline of the plain loop: ~10 us of loads + 3.4 us of rounds + W latency, nothing overlapped).
 constexpr int FOLD_KMAX = 512;   // input channels a block can fold statistics for (3 LDS tables)
-template <typename T, bool XF>
+template <typename T, bool XF, bool FAST = false>
 __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y,
                                                                    int HW, int tiles_per_img, int kchunks, InputXf xf,
                                                                    const T* __restrict__ addend, StatOut so,
@@ -822,8 +822,42 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __re
 
     uint4 xr[4];
     float4 wr[4];
+    uint32_t okbits = 0;   // FAST: bit it = weight chunk it is inside the slice, bit 4+it = X vector it is
     auto load_chunk = [&](int kc) {
         const int k0 = 64 * kc;
+        if constexpr (FAST) {
+            // K % 4 == 0 and M % 4 == 0 (launch conditions): every 16-byte chunk is wholly inside or outside the slice.
+            // Branch-free: an outside chunk reads the first chunk instead and is zeroed when it is written to LDS -- a
+            // conditional load ends its basic block with s_waitcnt vmcnt(0), which made the 4 weight requests of a
+            // round 4 serial L2 round trips
+            okbits = 0;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int q = tid + it * PW_THREADS;
+                long long off;
+                bool ok;
+                if (rowmajor) {
+                    const int r = q >> 4, kk = k0 + 4 * (q & 15);
+                    ok = r < mloc && kk < wv.K;
+                    off = (long long)(m_base + r) * wv.sm + kk;
+                } else {
+                    const int k = q >> 4, r = 4 * (q & 15);
+                    ok = k0 + k < wv.K && m_base + r < wv.M;
+                    off = (long long)(k0 + k) * wv.sk + m_base + r;
+                }
+                wr[it] = *reinterpret_cast<const float4*>(wv.w + (ok ? off : 0));
+                okbits |= (ok ? 1u : 0u) << it;
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int q = tid + it * PW_THREADS;
+                const int k = k0 + (q >> 4), px = p0 + 8 * (q & 15);
+                const bool ok = k < wv.K && px < HW;
+                xr[it] = *reinterpret_cast<const uint4*>(xn + (ok ? (long long)k * HW + px : 0));
+                okbits |= (ok ? 16u : 0u) << it;
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {   // weights first: vector-memory returns are in order
             const int q = tid + it * PW_THREADS;
@@ -862,6 +896,13 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __re
         }
     };
     auto store_chunk = [&](int kc) {
+        if constexpr (FAST) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                if (!((okbits >> it) & 1u)) wr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!((okbits >> (4 + it)) & 1u)) xr[it] = make_uint4(0, 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int q = tid + it * PW_THREADS;
@@ -919,6 +960,33 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __re
         __syncthreads();
         if (kc + 1 < kchunks) load_chunk(kc + 1);   // in flight during this round's MFMAs and the next barrier
         mma_round();
+    }
+    // a wave whose 32 rows x 64 pixels lie inside the tensor writes them as straight-line code: a store (or the addend's
+    // load) under a lane- or row-dependent branch ends its basic block with s_waitcnt vmcnt(0), i.e. 16 serial round trips
+    if (32 * cb + 32 <= mloc && p0 + PW_TILE <= HW && !(addend && so.partial)) {
+        const int px = p0 + 64 * hh + 2 * c;
+        T* yw = yn + (long long)(32 * cb) * HW + px;
+        if (addend) {
+            const T* aw = addend + ((long long)n * wv.M + m_base + 32 * cb) * HW + px;
+            uint32_t ar[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                ar[reg] = *reinterpret_cast<const uint32_t*>(aw + (long long)acc_row(reg, h) * HW);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                T lo, hi;
+                lo.v = (uint16_t)(ar[reg] & 0xffffu);
+                hi.v = (uint16_t)(ar[reg] >> 16);
+                acc[0][reg] += to_float(lo);
+                acc[1][reg] += to_float(hi);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            *reinterpret_cast<uint32_t*>(yw + (long long)acc_row(reg, h) * HW) = pack2<T>(acc[0][reg], acc[1][reg]);
+        // (statistics are of the conv output proper: with an addend as well the generic path below runs)
+        if (so.partial) stat_epilogue<T, 2>(acc, px, HW, c, h, 32 * cb, mloc, m_base, so, 2 * tile + hh);
+        return;
     }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -1249,8 +1317,13 @@ static void launch_gemm_v(const void* x, WView wv, void* y, int64_t HW, int tile
     } else {
         dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, 64));
         if constexpr (Elem<T>::is16 && AL && WV) {
-            hipLaunchKernelGGL((pw_fanin_pipe_kernel<T, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
-                               (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf, (const T*)addend, so, fold);
+            static const bool fast_ok = [] { const char* e = getenv("OFASR_PW_FANIN_FAST"); return !(e && e[0] == '0'); }();
+            if (fast_ok && wv.K % 4 == 0 && wv.M % 4 == 0)
+                hipLaunchKernelGGL((pw_fanin_pipe_kernel<T, XF, true>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv,
+                                   (T*)y, (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf, (const T*)addend, so, fold);
+            else
+                hipLaunchKernelGGL((pw_fanin_pipe_kernel<T, XF, false>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv,
+                                   (T*)y, (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf, (const T*)addend, so, fold);
             return;
         }
         hipLaunchKernelGGL((pw_fanin_kernel<T, AL, WV, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
