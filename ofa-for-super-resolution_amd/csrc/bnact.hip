@@ -227,9 +227,22 @@ __global__ void __launch_bounds__(BN_THREADS) bn_act_fwd_kernel(const T* __restr
             if (var < 0.0) var = 0.0;
         } else if (src.mode == 1) {
             double s = 0.0, ss = 0.0;
-            for (int q = 0; q < src.Pstat; ++q) {
-                s += src.partial[((long long)q * C + c) * 2];
-                ss += src.partial[((long long)q * C + c) * 2 + 1];
+            __shared__ double ps[2][BN_THREADS];   // one request per thread, in-order sum from LDS (see bn_bwd_apply_kernel)
+            if (src.Pstat <= BN_THREADS) {
+                if ((int)threadIdx.x < src.Pstat) {
+                    ps[0][threadIdx.x] = src.partial[((long long)threadIdx.x * C + c) * 2];
+                    ps[1][threadIdx.x] = src.partial[((long long)threadIdx.x * C + c) * 2 + 1];
+                }
+                __syncthreads();
+                for (int q = 0; q < src.Pstat; ++q) {
+                    s += ps[0][q];
+                    ss += ps[1][q];
+                }
+            } else {
+                for (int q = 0; q < src.Pstat; ++q) {
+                    s += src.partial[((long long)q * C + c) * 2];
+                    ss += src.partial[((long long)q * C + c) * 2 + 1];
+                }
             }
             mean = s / src.M;
             var = ss / src.M - mean * mean;
@@ -365,9 +378,24 @@ __global__ void __launch_bounds__(BN_THREADS) bn_bwd_apply_kernel(const T* __res
     const int c = blockIdx.x, p = blockIdx.y;
     const float sc = scale[c], mu = mean[c], is = invstd[c], sh = fmaf(mu, sc, shift[c]);
     double s = 0.0, sx = 0.0;
-    for (int q = 0; q < Pred; ++q) {
-        s += partial[((long long)q * C + c) * 2];
-        sx += partial[((long long)q * C + c) * 2 + 1];
+    // the channel's Pred partial pairs: one request per thread and an in-order sum from LDS (same order, same result as
+    // the serial loop, which costs Pred dependent L2 round trips before the block's first tensor request)
+    __shared__ double ps[2][BN_THREADS];
+    if (Pred <= BN_THREADS) {
+        if ((int)threadIdx.x < Pred) {
+            ps[0][threadIdx.x] = partial[((long long)threadIdx.x * C + c) * 2];
+            ps[1][threadIdx.x] = partial[((long long)threadIdx.x * C + c) * 2 + 1];
+        }
+        __syncthreads();
+        for (int q = 0; q < Pred; ++q) {
+            s += ps[0][q];
+            sx += ps[1][q];
+        }
+    } else {
+        for (int q = 0; q < Pred; ++q) {
+            s += partial[((long long)q * C + c) * 2];
+            sx += partial[((long long)q * C + c) * 2 + 1];
+        }
     }
     if (p == 0 && threadIdx.x == 0) {
         if (dgamma) dgamma[c] = (float)sx;

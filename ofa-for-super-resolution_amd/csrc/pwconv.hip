@@ -777,10 +777,21 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __re
             const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
             for (int ch = tid; ch < wv.K; ch += PW_THREADS) {
                 double s = 0.0, ss = 0.0;
-                for (int q = 0; q < fold.P; ++q) {
-                    const float2 v = fold.cp[(long long)ch * fold.P + q];
-                    s += (double)v.x;
-                    ss += (double)v.y;
+                // 8 partials per request round (clamped index, so the 8 loads are in flight together), summed in order:
+                // the same result as one load per iteration, which is P dependent L2 round trips per channel
+                for (int q0 = 0; q0 < fold.P; q0 += 8) {
+                    float2 v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int q = q0 + j < fold.P ? q0 + j : fold.P - 1;
+                        v[j] = fold.cp[(long long)ch * fold.P + q];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bool live = q0 + j < fold.P;
+                        s += live ? (double)v[j].x : 0.0;
+                        ss += live ? (double)v[j].y : 0.0;
+                    }
                 }
                 const double mean = s / fold.M;
                 double var = ss / fold.M - mean * mean;
