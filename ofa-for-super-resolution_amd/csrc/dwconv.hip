@@ -373,10 +373,20 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_mfma_kernel(const T* __restr
     if constexpr (XF) {
         if (fold.cp) {
             double s = 0.0, ss = 0.0;
-            for (int q = lane; q < fold.P; q += 64) {
-                const float2 v = fold.cp[(long long)c * fold.P + q];
-                s += (double)v.x;
-                ss += (double)v.y;
+            // 8 partials per lane and request round (clamped index: the loads are in flight together), same order
+            for (int q0 = lane; q0 < fold.P; q0 += 8 * 64) {
+                float2 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = q0 + 64 * j < fold.P ? q0 + 64 * j : fold.P - 1;
+                    v[j] = fold.cp[(long long)c * fold.P + q];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool live = q0 + 64 * j < fold.P;
+                    s += live ? (double)v[j].x : 0.0;
+                    ss += live ? (double)v[j].y : 0.0;
+                }
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
@@ -566,10 +576,20 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restri
         if (fold.cp) {
             // the input BN's finalize, per wave: channel c from its P partials (lanes stride, fp64 butterfly: fixed order)
             double s = 0.0, ss = 0.0;
-            for (int q = lane; q < fold.P; q += 64) {
-                const float2 v = fold.cp[(long long)c * fold.P + q];
-                s += (double)v.x;
-                ss += (double)v.y;
+            // 8 partials per lane and request round (clamped index: the loads are in flight together), same order
+            for (int q0 = lane; q0 < fold.P; q0 += 8 * 64) {
+                float2 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = q0 + 64 * j < fold.P ? q0 + 64 * j : fold.P - 1;
+                    v[j] = fold.cp[(long long)c * fold.P + q];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool live = q0 + 64 * j < fold.P;
+                    s += live ? (double)v[j].x : 0.0;
+                    ss += live ? (double)v[j].y : 0.0;
+                }
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
