@@ -296,7 +296,7 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
         }
         if (rc) return rc;
         const StatOut so3{(pw_stat && d->bn_training[2]) ? part : nullptr, P3};
-        if (d->bn_training[1] && pwconv_fold_supported(y2, y3, d->w2, d->ldw2, d->mid, HW, d->dtype)) {
+        if (d->bn_training[1] && d->Cout % 4 == 0 && pwconv_fold_supported(y2, y3, d->w2, d->ldw2, d->mid, HW, d->dtype)) {
             // BN2's finalize is folded into the project kernel's blocks (16 partials per channel)
             StatView sv = stat_view(stat_buf, 1, d->mid, d->Cout);
             rc = pwconv_fwd_fold(y2, d->w2, d->ldw2, y3, d->N, d->mid, d->Cout, HW, d->dtype,

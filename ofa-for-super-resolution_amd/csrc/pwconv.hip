@@ -439,43 +439,44 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restri
         const int tid = threadIdx.x;
         const bool rowmajor = wv.sk == 1;
         float4 wr[8];
+        // WVEC implies K % 4 == 0 and M % 4 == 0 (launch_gemm): every 16-byte chunk is wholly inside or outside the slice -> branch-free requests
+        // (clamped address, zeroed when written to LDS); a conditional load ends its basic block with s_waitcnt
+        // vmcnt(0), which turns the requests below into serial round trips
+        uint32_t okbits = 0;
+        {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int q = tid + it * PW_THREADS;
-            wr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rowmajor) {
-                const int r = q >> 4, kk = 4 * (q & 15);
-                if (r < mloc) {
-                    const float* src = wv.w + (long long)(m_base + r) * wv.sm + kk;
-                    if (kk + 3 < wv.K) wr[it] = *reinterpret_cast<const float4*>(src);
-                    else {
-                        if (kk < wv.K) wr[it].x = src[0];
-                        if (kk + 1 < wv.K) wr[it].y = src[1];
-                        if (kk + 2 < wv.K) wr[it].z = src[2];
-                    }
+            for (int it = 0; it < 8; ++it) {
+                const int q = tid + it * PW_THREADS;
+                long long off;
+                bool ok;
+                if (rowmajor) {
+                    const int r = q >> 4, kk = 4 * (q & 15);
+                    ok = r < mloc && kk < wv.K;
+                    off = (long long)(m_base + r) * wv.sm + kk;
+                } else {
+                    const int k = q >> 5, r = 4 * (q & 31);
+                    ok = k < wv.K && m_base + r < wv.M;
+                    off = (long long)k * wv.sk + m_base + r;
                 }
-            } else {
-                const int k = q >> 5, r = 4 * (q & 31);
-                const int m = m_base + r;
-                if (k < wv.K) {
-                    const float* src = wv.w + (long long)k * wv.sk + m;
-                    if (m + 3 < wv.M) wr[it] = *reinterpret_cast<const float4*>(src);
-                    else {
-                        if (m < wv.M) wr[it].x = src[0];
-                        if (m + 1 < wv.M) wr[it].y = src[1];
-                        if (m + 2 < wv.M) wr[it].z = src[2];
-                    }
-                }
+                wr[it] = *reinterpret_cast<const float4*>(wv.w + (ok ? off : 0));
+                okbits |= (ok ? 1u : 0u) << it;
             }
         }
         uint4 xr[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < 4; ++it) {   // HW % 8 == 0 (ALIGNED): a vector is wholly inside or outside the plane
             const int q = tid + it * PW_THREADS;
             const int k = q >> 4, px = p0 + 8 * (q & 15);
-            xr[it] = make_uint4(0, 0, 0, 0);
-            if (k < wv.K && px < HW) xr[it] = *reinterpret_cast<const uint4*>(xn + (long long)k * HW + px);
+            const bool ok = k < wv.K && px < HW;
+            xr[it] = *reinterpret_cast<const uint4*>(xn + (ok ? (long long)k * HW + px : 0));
+            okbits |= (ok ? 256u : 0u) << it;
         }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            if (!((okbits >> (8 + it)) & 1u)) xr[it] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            if (!((okbits >> it) & 1u)) wr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int q = tid + it * PW_THREADS;
@@ -541,6 +542,20 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanout_kernel(const T* __restri
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b4.z, acc[2], 0, 0, 0);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], b4.w, acc[3], 0, 0, 0);
             }
+        }
+    }
+    if constexpr (Elem<T>::is16 && ALIGNED) {
+        // a wave whose 32 rows x 128 pixels lie inside the tensor writes them as straight-line code (no store or addend
+        // load under a lane- or row-dependent branch: each would be a serial round trip)
+        if (32 * cb + 32 <= mloc && p0 + PW_TILE <= HW && addend == nullptr) {
+            const int px = p0 + 4 * c;
+            T* yw = yn + (long long)(32 * cb) * HW + px;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                *reinterpret_cast<uint2*>(yw + (long long)acc_row(reg, h) * HW) =
+                    make_uint2(pack2<T>(acc[0][reg], acc[1][reg]), pack2<T>(acc[2][reg], acc[3][reg]));
+            if (so.partial) stat_epilogue<T, 4>(acc, px, HW, c, h, 32 * cb, mloc, m_base, so, tile);
+            return;
         }
     }
 #pragma unroll
@@ -1349,7 +1364,8 @@ static int launch_gemm(const char* name, const void* x, WView wv, void* y, int64
     constexpr bool is16 = Elem<T>::is16;
     const bool al = aligned_for(x, y, HW, is16);
     const long long ld = wv.sk == 1 ? wv.sm : wv.sk;
-    const bool wvec = (reinterpret_cast<uintptr_t>(wv.w) & 15) == 0 && (ld % 4) == 0;
+    // vector weight staging: 16-byte aligned rows AND K, M multiples of 4, so that a chunk never straddles the slice
+    const bool wvec = (reinterpret_cast<uintptr_t>(wv.w) & 15) == 0 && (ld % 4) == 0 && wv.K % 4 == 0 && wv.M % 4 == 0;
     const int tiles_per_img = (int)cdiv(HW, PW_TILE);
     const int64_t total64 = N * tiles_per_img;
     OFASR_REQUIRE(total64 <= INT32_MAX, OFASR_ERR_UNSUPPORTED, "%s: too many pixel tiles", name);
@@ -1482,7 +1498,7 @@ int pwconv_fwd_stat(const void* x, const float* w, int64_t ldw, void* y, int64_t
 
 bool pwconv_fold_supported(const void* x, const void* y, const float* w, int64_t ldw, int64_t Cin, int64_t HW, int dtype) {
     const bool wvec = (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (ldw % 4) == 0;
-    return pwconv_xf_supported(x, y, HW, dtype) && wvec && Cin > 64 && Cin <= FOLD_KMAX;
+    return pwconv_xf_supported(x, y, HW, dtype) && wvec && Cin > 64 && Cin <= FOLD_KMAX && Cin % 4 == 0;
 }
 
 int pwconv_fwd_fold(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin, int64_t Cout,
