@@ -215,8 +215,10 @@ def main():
 def kernel_symbol(call):
     """HIP kernel run by a single-launch API call of the timer table (None for multi-kernel calls)."""
     if call.startswith("pwconv_fwd_") or call.startswith("pwconv_dgrad_"):
-        k_red = int(call.split("_")[2].split("to")[0])      # reduction width
-        return "pw_fanout_kernel" if k_red <= 64 else "pw_fanin_pipe_kernel"   # 16-bit aligned path
+        k_red, m_out = (int(v) for v in call.split("_")[2].split("to"))      # reduction width, output rows
+        if k_red <= 64:   # 16-bit aligned path: whole 128-row slabs of a 64-wide reduction take the slab-walk kernel
+            return "pw_fanout_slabs_kernel" if (k_red == 64 and m_out % 128 == 0 and m_out > 128) else "pw_fanout_kernel"
+        return "pw_fanin_pipe_kernel"
     if call.startswith("dwconv_fwd_k") or call.startswith("dwconv_dgrad_k"):
         return "dw_vec_kernel<K=%s>" % call.rsplit("k", 1)[1]
     return {"pixel_shuffle": "ps_r2_kernel", "pixel_unshuffle": "ps_r2_kernel"}.get(call)

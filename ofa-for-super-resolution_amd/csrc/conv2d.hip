@@ -81,6 +81,11 @@ __global__ void __launch_bounds__(256) conv_prep_kernel(const float* __restrict_
     wimg[idx] = from_float<T>(v);
 }
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the wave's outstanding global loads and
+// stores (vmcnt(0)), i.e. it would wait for the A fragments requested just before it instead of letting their L2 latency
+// hide behind the staging of the window
+__device__ __forceinline__ void cv_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <typename T, int KS, int RB, int WM, int WP, bool ONEK>
 __global__ void __launch_bounds__(64 * WM * WP, 2) conv_igemm_kernel(const T* __restrict__ x, const T* __restrict__ wimg,
                                                                      T* __restrict__ y, int Cx, int M, int H, int W,
@@ -145,7 +150,7 @@ __global__ void __launch_bounds__(64 * WM * WP, 2) conv_igemm_kernel(const T* __
             for (int rb = 0; rb < RB; ++rb)
                 A[tx][rb] = __builtin_bit_cast(cv_s16x8, (wk + ((long long)tx * nrb + rb) * 64)[lane]);
 
-        __syncthreads();   // previous chunk's readers are done with Xt
+        cv_lds_barrier();   // previous chunk's readers are done with Xt (LDS only: the A requests above stay in flight)
         // ---- stage the window of channels [32kc, 32kc+32): task = (8-channel group, window row, 8-column run);
         //      8 x 16-byte loads, 8x8 16-bit transpose in registers, 8 x 16-byte record stores
         constexpr int NRUN = (CV_TW + 16) / 8;   // 10 runs cover columns [tx0-8, tx0+72)
@@ -184,7 +189,7 @@ __global__ void __launch_bounds__(64 * WM * WP, 2) conv_igemm_kernel(const T* __
                     *reinterpret_cast<uint4*>(Xt + cv_rec(cv_pos(r, tc0 + 1), g)) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
             }
         }
-        __syncthreads();
+        cv_lds_barrier();
 
         // (ty, k-step) iterations; ONEK (K <= 16: the 3-channel stem / head gradient) walks k-step 0 only
         constexpr int STEP = ONEK ? 2 : 1;

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--N", type=int, default=16)
     ap.add_argument("--S", type=int, default=64)
+    ap.add_argument("--mid", type=int, default=384, help="expanded width (192 / 256 / 384 for e = 3 / 4 / 6)")
     a = ap.parse_args()
     import torch
     C = importlib.import_module(PKG + "._C")
@@ -31,14 +32,14 @@ def main():
     code = {"bf16": 2, "f32": 0, "f16": 1}[a.dtype]
     es = 2 if a.dtype != "f32" else 4
     dev = "cuda:0"
-    N, S, mid = a.N, a.S, 384
+    N, S, mid = a.N, a.S, a.mid
     HW = S * S
     x64 = torch.randn(N, 64, S, S, device=dev).to(dt)
     xm = torch.randn(N, mid, S, S, device=dev).to(dt)
     ym = torch.empty_like(xm)
     y64 = torch.empty_like(x64)
-    w1 = torch.randn(384, 64, 1, 1, device=dev) * 0.1
-    w2 = torch.randn(64, 384, 1, 1, device=dev) * 0.1
+    w1 = torch.randn(mid, 64, 1, 1, device=dev) * 0.1
+    w2 = torch.randn(64, mid, 1, 1, device=dev) * 0.1
     dw1 = torch.zeros_like(w1)
     dw2 = torch.zeros_like(w2)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -47,18 +48,18 @@ def main():
     wsn = ctypes.c_size_t(ws.numel())
     cases = []
     act_big = (N * (64 + mid) * HW) * es
-    cases.append(("pwconv_fwd 64->384", act_big + 4 * 64 * mid,
+    cases.append(("pwconv_fwd 64->mid", act_big + 4 * 64 * mid,
                   lambda: L.ofasr_pwconv_fwd(P(x64), P(w1), 64, P(ym), N, 64, mid, HW, code, st)))
-    cases.append(("pwconv_fwd 384->64", act_big + 4 * 64 * mid,
-                  lambda: L.ofasr_pwconv_fwd(P(xm), P(w2), 384, P(y64), N, mid, 64, HW, code, st)))
-    cases.append(("pwconv_dgrad 384->64 (of expand)", act_big,
+    cases.append(("pwconv_fwd mid->64", act_big + 4 * 64 * mid,
+                  lambda: L.ofasr_pwconv_fwd(P(xm), P(w2), mid, P(y64), N, mid, 64, HW, code, st)))
+    cases.append(("pwconv_dgrad mid->64 (of expand)", act_big,
                   lambda: L.ofasr_pwconv_dgrad(P(xm), P(w1), 64, P(y64), N, 64, mid, HW, code, st)))
-    cases.append(("pwconv_dgrad 64->384 (of project)", act_big,
-                  lambda: L.ofasr_pwconv_dgrad(P(x64), P(w2), 384, P(ym), N, mid, 64, HW, code, st)))
+    cases.append(("pwconv_dgrad 64->mid (of project)", act_big,
+                  lambda: L.ofasr_pwconv_dgrad(P(x64), P(w2), mid, P(ym), N, mid, 64, HW, code, st)))
     cases.append(("pwconv_wgrad expand", act_big,
                   lambda: L.ofasr_pwconv_wgrad(P(xm), P(x64), P(dw1), 64, N, 64, mid, HW, code, P(ws), wsn, st)))
     cases.append(("pwconv_wgrad project", act_big,
-                  lambda: L.ofasr_pwconv_wgrad(P(x64), P(xm), P(dw2), 384, N, mid, 64, HW, code, P(ws), wsn, st)))
+                  lambda: L.ofasr_pwconv_wgrad(P(x64), P(xm), P(dw2), mid, N, mid, 64, HW, code, P(ws), wsn, st)))
     for K in (3, 5, 7):
         f = torch.randn(mid, 1, K, K, device=dev) * 0.1
         df = torch.zeros_like(f)
