@@ -413,11 +413,33 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
             if (rc) return rc;
         }
     }
+    // With the side stream the fill leaves the input-gradient chain: the three weight-gradient buffers are written by
+    // side-stream kernels only, so they are cleared there (after fork(0) below); the six BN-gradient vectors are written
+    // in full by the chain's BN kernels unless the BN is sliced (then their tails are cleared here).
+    auto fill = [&](int i0, int i1, hipStream_t stream_) -> hipError_t {
+        char *l = sp[i0].p, *h = sp[i0].p + sp[i0].n;
+        size_t tot = 0;
+        for (int i = i0; i < i1; ++i) {
+            l = sp[i].p < l ? sp[i].p : l;
+            h = sp[i].p + sp[i].n > h ? sp[i].p + sp[i].n : h;
+            tot += sp[i].n;
+        }
+        if ((size_t)(h - l) == tot) return hipMemsetAsync(l, 0, tot, stream_);   // adjacent spans: one fill
+        hipError_t er = hipSuccess;
+        for (int i = i0; i < i1 && er == hipSuccess; ++i) er = hipMemsetAsync(sp[i].p, 0, sp[i].n, stream_);
+        return er;
+    };
+    const bool split_fill = ss.enabled;
+    const bool bn_sliced = d->mid < d->Cmid_max || d->Cout < d->Cout_max;
     hipError_t e = hipSuccess;
-    if ((size_t)(hi - lo) == sum) {   // disjoint spans (validated above) tiling [lo, hi) exactly
-        e = hipMemsetAsync(lo, 0, sum, st);
-    } else {
-        for (int i = 0; i < 9 && e == hipSuccess; ++i) e = hipMemsetAsync(sp[i].p, 0, sp[i].n, st);
+    if (!split_fill) {
+        if ((size_t)(hi - lo) == sum) {   // disjoint spans (validated above) tiling [lo, hi) exactly
+            e = hipMemsetAsync(lo, 0, sum, st);
+        } else {
+            for (int i = 0; i < 9 && e == hipSuccess; ++i) e = hipMemsetAsync(sp[i].p, 0, sp[i].n, st);
+        }
+    } else if (bn_sliced) {
+        e = fill(3, 9, st);
     }
     OFASR_REQUIRE(e == hipSuccess, OFASR_ERR_LAUNCH, "%s: memset failed: %s", name, hipGetErrorString(e));
 
@@ -444,8 +466,12 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
         OFASR_REQUIRE((reinterpret_cast<uintptr_t>(tmp_buf) & 15) == 0, OFASR_ERR_UNSUPPORTED,
                       "%s: tmp_buf must be 16-byte aligned (the forward pass did not materialise the activations)", name);
     // project 1x1: weight gradient (side) beside input gradient + BN2 backward (main)
-    rc = fork(0);   // dy3 (t3) and the zeroed gradient buffers are final
+    rc = fork(0);   // dy3 (t3) is final
     if (rc) return rc;
+    if (split_fill) {
+        const hipError_t ef = fill(0, 3, (hipStream_t)sst);
+        OFASR_REQUIRE(ef == hipSuccess, OFASR_ERR_LAUNCH, "%s: memset failed: %s", name, hipGetErrorString(ef));
+    }
     if (fused)
         rc = pwconv_wgrad_xf(t3, y2, g->dw2, d->ldw2, d->N, d->mid, d->Cout, HW, d->dtype,
                              xf_of(stat_buf, 1, d->mid, d->Cout), side_ws, s.side, sst);
