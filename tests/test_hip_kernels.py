@@ -260,6 +260,9 @@ PW_CASES = [
     (1, 3, 5, 8, 8, 5, 5),            # tiny / odd everything
     (1, 100, 70, 128, 96, 9, 8),      # K > 64 and M > 64: generic fan-in over 2 row passes
     (1, 64, 64, 64, 64, 64, 64),      # one full LR image
+    (2, 64, 256, 64, 384, 16, 16),    # expand to 2 whole 128-row slabs on whole 128-pixel tiles: slab-walk kernel, NSLAB = 2
+    (2, 256, 64, 384, 64, 16, 16),    # its project (input gradient = the same kernel with K = 64)
+    (1, 64, 192, 64, 384, 16, 16),    # 1.5 slabs: generic fan-out kernel with branch-free requests, full and partial waves
 ]
 
 
