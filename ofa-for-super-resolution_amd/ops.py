@@ -445,11 +445,19 @@ def _flush_deferred():
     _Deferred.ext_used = set()
     grads, _Deferred.grads, _Deferred.keep = _Deferred.grads, [], []
     with torch.no_grad():
+        acc_dst, acc_src, seen = [], [], set()
         for p, g in grads:
             if p.grad is None:
                 p.grad = g
-            else:
+            elif id(p) in seen:        # a parameter used by two blocks: keep its adds ordered
                 p.grad.add_(g)
+            else:                      # gradient accumulation / the data-parallel bucket's views
+                seen.add(id(p))
+                acc_dst.append(p.grad)
+                acc_src.append(g)
+        if acc_dst:                    # one multi-tensor launch instead of one add per parameter
+            torch._foreach_add_(acc_dst, acc_src)
+        for p, _ in grads:
             hooks = getattr(p, "_post_accumulate_grad_hooks", None)
             if hooks:
                 for h in list(hooks.values()):
