@@ -94,7 +94,7 @@ def main():
     no_decay = list(net.get_parameters(["bn", "bias"], mode="include"))
     opt = torch.optim.Adam([{"params": decay, "weight_decay": 3e-5}, {"params": no_decay, "weight_decay": 0}],
                            lr=1e-3, fused=True if os.environ.get("OFASR_FUSED_ADAM", "1") != "0" else None)
-    reducer = dd.FlatGradReducer(net.parameters()) if world > 1 else None
+    reducer = dd.FlatGradReducer(net.parameters(), gather=True) if world > 1 else None
 
     act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     N, S = args.batch, args.lr_size

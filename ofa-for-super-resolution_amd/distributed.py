@@ -63,7 +63,12 @@ class FlatGradReducer(object):
             optimizer.step()
     """
 
-    def __init__(self, params, process_group=None):
+    def __init__(self, params, process_group=None, gather=False):
+        # gather=False: every .grad is a view of the bucket during backward (autograd accumulates into it: one small
+        #   add per parameter and backward node).  gather=True: backward runs with .grad = None (autograd hands the
+        #   gradient tensors over without a kernel); reduce() zeroes the bucket and copies all gradients in with ONE
+        #   multi-tensor copy -- ~250 fewer launches per step on the GPU, same result, same .grad views afterwards.
+        self.gather = bool(gather)
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatGradReducer needs at least one trainable parameter")
@@ -92,6 +97,11 @@ class FlatGradReducer(object):
 
     def prepare(self):
         """zero the bucket and point every .grad at its slice (replaces optimizer.zero_grad())."""
+        if self.gather:
+            for i, p in enumerate(self.params):
+                p.grad = None
+                self._touched[i] = False
+            return
         self.flat.zero_()
         for i, (p, v) in enumerate(zip(self.params, self.views)):
             p.grad = v
@@ -103,6 +113,17 @@ class FlatGradReducer(object):
     def reduce(self, average=True):
         """one all-reduce over the whole bucket; afterwards parameters that received no gradient in
         this step have .grad None (so Adam skips them, as in the reference)."""
+        if self.gather:
+            self.flat.zero_()
+            dst = [v for p, v in zip(self.params, self.views) if p.grad is not None]
+            src = [p.grad for p in self.params if p.grad is not None]
+            self._touched = [p.grad is not None for p in self.params]
+            if dst:
+                with torch.no_grad():
+                    torch._foreach_copy_(dst, src)
+            for p, v, t in zip(self.params, self.views, self._touched):
+                if t:
+                    p.grad = v
         if is_distributed():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             if average:

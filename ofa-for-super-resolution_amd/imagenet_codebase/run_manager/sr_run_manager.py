@@ -163,7 +163,7 @@ class SRRunManager(object):
         else:
             net_params = list(self.network.weight_parameters())
         self.optimizer = self.run_config.build_optimizer(net_params)
-        self.reducer = dd.FlatGradReducer(self.network.parameters()) if dd.is_distributed() else None
+        self.reducer = dd.FlatGradReducer(self.network.parameters(), gather=True) if dd.is_distributed() else None
 
     # ------------------------------------------------------------------ distributed helpers
     @property

@@ -32,7 +32,7 @@ class _Elastic(nn.Module):
         return self.c(x)
 
 
-def _worker(rank, world, init_file, out_dir):
+def _worker(rank, world, init_file, out_dir, gather=False):
     sys.path.insert(0, ROOT)
     import importlib
     dd = importlib.import_module(PKG + ".distributed")
@@ -47,7 +47,7 @@ def _worker(rank, world, init_file, out_dir):
         for p, q in zip(net.parameters(), ref.parameters()):
             assert torch.equal(p, q), "broadcast_module must copy rank 0's parameters"
 
-        reducer = dd.FlatGradReducer(net.parameters())
+        reducer = dd.FlatGradReducer(net.parameters(), gather=gather)
         assert reducer.nbytes == 4 * sum(p.numel() for p in net.parameters())
         opt = torch.optim.Adam(net.parameters(), lr=1e-2, weight_decay=1e-2)
         g = torch.Generator().manual_seed(7)
@@ -90,10 +90,13 @@ def _worker(rank, world, init_file, out_dir):
         dist.destroy_process_group()
 
 
-def test_flat_grad_reducer_two_ranks_gloo():
+@pytest.mark.parametrize("gather", [False, True])
+def test_flat_grad_reducer_two_ranks_gloo(gather):
+    """gather=False: .grad are bucket views during backward; gather=True (what the GPU trainers use): gradients are
+    copied into the bucket by one multi-tensor copy in reduce().  Same DP step either way."""
     with tempfile.TemporaryDirectory() as d:
         init_file = os.path.join(d, "rendezvous")
-        mp.spawn(_worker, args=(2, init_file, d), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, init_file, d, gather), nprocs=2, join=True)
         assert os.path.exists(os.path.join(d, "ok0")) and os.path.exists(os.path.join(d, "ok1"))
 
 
@@ -106,9 +109,23 @@ def test_reducer_single_process_semantics():
     net.depth = 1
     red.prepare()
     assert all(p.grad is not None for p in net.parameters())
-    net(torch.randn(3, 6)).sum().backward()
+    xin = torch.randn(3, 6)
+    net(xin).sum().backward()
     red.reduce()
     assert [p.grad is None for p in net.parameters()] == [False, False, True, True, False, False]
     # gradients are views of one flat buffer
     assert net.a.weight.grad.data_ptr() == red.flat.data_ptr()
+    # gather mode: no .grad during backward, the same views and None-ness after reduce()
+    want = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+    red.remove()
+    red2 = dd.FlatGradReducer(net.parameters(), gather=True)
+    red2.prepare()
+    assert all(p.grad is None for p in net.parameters())
+    net(xin).sum().backward()
+    red2.reduce()
+    for p, w in zip(net.parameters(), want):
+        assert (p.grad is None) == (w is None)
+        if w is not None:
+            assert torch.equal(p.grad, w)
+    assert net.a.weight.grad.data_ptr() == red2.flat.data_ptr()
     assert dd.world_size() == 1 and dd.rank() == 0 and not dd.is_distributed()
