@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- OFA-SR progressive-shrinking training throughput on MI355X.
+"""bench.py -- OFA-SR supernet hot path on MI355X: training throughput (BASELINE metric) and the other BASELINE configs.
 
     python bench.py --gpus N --steps K --warmup W          (N = 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-Metric (BASELINE.json): SR training images/sec, 64x64 -> 256x256 (4x), whole-job aggregate.
-One "step" = one pass of the hot path over one synthetic mini-batch per GPU: sample a
-sub-network (seed rule of the reference, progressive_shrinking.py:164), forward, MSE loss,
-backward, gradient all-reduce (N > 1), Adam step.  Inputs are resident in HBM before the timed
-region.  Prints ONE JSON line on rank 0 with `roofline` (dominant HIP kernel, timed with events on
-the launch stream) and `cpu_baseline` (the CPU oracle port of the same training step, timed on
-the host cores in this run).
+--config c3 (default; BASELINE.json `metric`): SR training images/sec, 64x64 -> 256x256 (4x), whole-job aggregate.
+    One "step" = one pass of the hot path over one synthetic mini-batch per GPU: sample a sub-network (seed rule of the
+    reference, progressive_shrinking.py:164), forward, MSE loss, backward, gradient all-reduce (N > 1), Adam step.
+    Inputs are resident in HBM before the timed region.
+--config c2: S4 2x supernet, fixed sub-network k=3 / d=4 / e=6, LR 48x48 -> HR 96x96, one training step per step.
+--config c5: sampled sub-network (ks=7, e=6, d=2, pixel_d=2) 4x inference over the 14 Set14 image sizes, eval mode,
+    images of equal size batched together (eval_ofa_net_sr.py); a "step" is one pass over the 14 images.
+
+Prints ONE JSON line on rank 0.  Besides the contract fields it carries
+  roofline      the kernel of the HIP library with the largest total time over the profiled steps (ALL library kernels
+                compete, on whichever stream they ran), timed live with HIP events recorded on the stream each kernel is
+                launched on (ofasr_profile_enable, include/ofasr.h) on the SAME composite path the timed region runs;
+  kernels       the per-kernel table of those profiled steps (symbol = the name rocprofv3 prints);
+  pointwise     the 1x1 path's MFMA TFLOP/s against the bf16 MFMA peak (north_star quotes its target against it);
+  fp32          (c3, dtype != f32) the same training step with fp32 activations -- the reference's arithmetic;
+  cpu_baseline  the CPU oracle port of the same training step timed on the host cores in this run.
 """
 import argparse
 import importlib
@@ -28,219 +37,237 @@ PKG = "ofa-for-super-resolution_amd"
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 MFMA_PEAK_TF = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}
 
+# HR sizes (H, W) of the 14 Set14 images after ModCrop(4) (div2k_setxx.py:182-190); LR = HR / 4
+SET14_HR = [(480, 500), (576, 720), (512, 512), (288, 352), (360, 248), (276, 276), (360, 500), (288, 352),
+            (512, 512), (512, 512), (512, 768), (512, 512), (656, 528), (388, 584)]
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--config", default="c3", choices=["c3", "c2", "c5"])
     ap.add_argument("--batch", type=int, default=16, help="images per GPU (reference train_batch_size 16)")
-    ap.add_argument("--lr-size", type=int, default=64)
+    ap.add_argument("--lr-size", type=int, default=None, help="LR crop side (c3: 64, c2: 48)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-activation leg of the c3 line")
+    ap.add_argument("--fp32-steps", type=int, default=10)
     ap.add_argument("--h2d", action="store_true", help="copy the batch from pinned host memory inside every timed step "
                                                        "(the PCIe-inclusive rate quoted in DESIGN.md; never `value`)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                                                       "the N>1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-images", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def subnet_seed(step, sub=0):
     return int("%d%.3d%.3d" % (step, sub, 0))   # progressive_shrinking.py:164
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
-    import torch.nn.functional as F
+def mods():
+    m = {k: importlib.import_module(PKG + "." + k) for k in ("_C", "ops", "distributed")}
+    m["dop"] = importlib.import_module(PKG + ".elastic_nn.modules.dynamic_op")
+    m["nets"] = importlib.import_module(PKG + ".elastic_nn.networks")
+    return m
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
-        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-        if args.backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+class TrainWorkload(object):
+    """the training step of configs c3 / c2: same objects for the timed leg, the fp32 leg and tests/test_bench_step.py"""
+
+    def __init__(self, M, config, dev, batch, lr_size, dtype, world=1, rank=0, h2d=False, seed=0):
+        import torch
+        import torch.nn.functional as F
+        self.torch, self.F, self.M = torch, F, M
+        self.config, self.dev, self.N, self.S, self.world = config, dev, batch, lr_size, world
+        self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtype]
+        torch.manual_seed(seed)
+        random.seed(seed)
+        M["dop"].DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = 1            # train_ofa_net_sr_simple.py:183
+        if config == "c3":
+            net = M["nets"].OFAMobileNetS4(ks_list=[3, 5, 7], expand_ratio_list=[6], depth_list=[4],
+                                           pixelshuffle_depth_list=[2])
+            self.scale, self.fixed = 4, None
+        else:   # c2: 2x supernet, fixed k=3 / e=6 / d=4
+            net = M["nets"].OFAMobileNetS4(ks_list=[3, 5, 7], expand_ratio_list=[3, 4, 6], depth_list=[2, 3, 4],
+                                           pixelshuffle_depth_list=[1])
+            self.scale, self.fixed = 2, dict(ks=3, e=6, d=4, pixel_d=1)
+        net.init_model("he_fout")
+        net.to(dev).train()
+        M["distributed"].broadcast_module(net)
+        self.net = net
+        self.n_params = sum(p.numel() for p in net.parameters())
+        # optimizer: Adam, weight decay 3e-5 except on names with 'bn' / 'bias' (sr_run_manager.py:180-191)
+        decay = list(net.get_parameters(["bn", "bias"], mode="exclude"))
+        no_decay = list(net.get_parameters(["bn", "bias"], mode="include"))
+        self.opt = torch.optim.Adam([{"params": decay, "weight_decay": 3e-5}, {"params": no_decay, "weight_decay": 0}],
+                                    lr=1e-3, fused=True if os.environ.get("OFASR_FUSED_ADAM", "1") != "0" else None)
+        self.reducer = M["distributed"].FlatGradReducer(net.parameters(), gather=True) if world > 1 else None
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        hr = torch.rand((batch, 3, self.scale * lr_size, self.scale * lr_size), generator=g)
+        lr = F.interpolate(hr, scale_factor=1.0 / self.scale, mode="bicubic", antialias=True).clamp_(0, 1)
+        self.hr_host, self.lr_host = (hr.pin_memory(), lr.pin_memory()) if h2d else (None, None)
+        self.hr, self.lr = hr.to(dev), lr.to(dev)
+        if self.fixed is not None:
+            net.set_active_subnet(**self.fixed)
+
+    def step(self, i):
+        torch, F = self.torch, self.F
+        if self.hr_host is not None:   # what the reference's loader hands over: host tensors
+            self.hr.copy_(self.hr_host, non_blocking=True)
+            self.lr.copy_(self.lr_host, non_blocking=True)
+        if self.reducer is not None:
+            self.reducer.prepare()
         else:
-            local_rank = local_rank % max(torch.cuda.device_count(), 1)   # rehearsal: ranks may share a GPU
-            dist.init_process_group(args.backend)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-
-    C = importlib.import_module(PKG + "._C")
-    C.lib()   # fail loudly if the HIP extension is missing
-    ops = importlib.import_module(PKG + ".ops")
-    dop = importlib.import_module(PKG + ".elastic_nn.modules.dynamic_op")
-    nets = importlib.import_module(PKG + ".elastic_nn.networks")
-    dd = importlib.import_module(PKG + ".distributed")
-
-    torch.manual_seed(0)
-    random.seed(0)
-    torch.backends.cudnn.benchmark = True                           # sr_run_manager.py:153 (MIOpen find mode)
-    dop.DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = 1            # train_ofa_net_sr_simple.py:183
-    net = nets.OFAMobileNetS4(ks_list=[3, 5, 7], expand_ratio_list=[6], depth_list=[4], pixelshuffle_depth_list=[2])
-    net.init_model("he_fout")
-    net.to(dev).train()
-    dd.broadcast_module(net)
-    n_params = sum(p.numel() for p in net.parameters())
-
-    # optimizer: Adam, weight decay 3e-5 except on names with 'bn' / 'bias' (sr_run_manager.py:180-191)
-    decay = list(net.get_parameters(["bn", "bias"], mode="exclude"))
-    no_decay = list(net.get_parameters(["bn", "bias"], mode="include"))
-    opt = torch.optim.Adam([{"params": decay, "weight_decay": 3e-5}, {"params": no_decay, "weight_decay": 0}],
-                           lr=1e-3, fused=True if os.environ.get("OFASR_FUSED_ADAM", "1") != "0" else None)
-    reducer = dd.FlatGradReducer(net.parameters(), gather=True) if world > 1 else None
-
-    act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
-    N, S = args.batch, args.lr_size
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    hr = torch.rand((N, 3, 4 * S, 4 * S), generator=g)
-    lr = F.interpolate(hr, scale_factor=0.25, mode="bicubic", antialias=True).clamp_(0, 1)
-    hr_host, lr_host = (hr.pin_memory(), lr.pin_memory()) if args.h2d else (None, None)
-    hr, lr = hr.to(dev), lr.to(dev)
-
-    def train_step(step):
-        if args.h2d:   # what the reference's loader hands over: host tensors
-            hr.copy_(hr_host, non_blocking=True)
-            lr.copy_(lr_host, non_blocking=True)
-        if reducer is not None:
-            reducer.prepare()
+            self.opt.zero_grad(set_to_none=True)
+        if self.fixed is None:
+            random.seed(subnet_seed(i))
+            self.net.sample_active_subnet()
+        if self.act_dtype == torch.float32:
+            out = self.net(self.lr)
+            loss = F.mse_loss(out, self.hr)
         else:
-            opt.zero_grad(set_to_none=True)
-        random.seed(subnet_seed(step))
-        net.sample_active_subnet()
-        if act_dtype == torch.float32:
-            out = net(lr)
-            loss = F.mse_loss(out, hr)
-        else:
-            with torch.autocast("cuda", dtype=act_dtype):
-                out = net(lr)
-            loss = F.mse_loss(out.float(), hr)
+            with torch.autocast("cuda", dtype=self.act_dtype):
+                out = self.net(self.lr)
+            loss = F.mse_loss(out.float(), self.hr)
         loss.backward()
-        if reducer is not None:
-            reducer.reduce()
-        opt.step()
+        if self.reducer is not None:
+            self.reducer.reduce()
+        self.opt.step()
         return loss
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        train_step(i)
+class EvalWorkload(object):
+    """config c5: eval_ofa_net_sr.py's sub-network over the Set14 sizes, equal sizes batched (size buckets)"""
+
+    def __init__(self, M, dev, dtype, seed=0):
+        import torch
+        self.torch, self.M, self.dev = torch, M, dev
+        self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtype]
+        torch.manual_seed(seed)
+        M["dop"].DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = 1
+        net = M["nets"].OFAMobileNetS4(ks_list=[3, 5, 7], expand_ratio_list=[3, 4, 6], depth_list=[2, 3, 4],
+                                       pixelshuffle_depth_list=[1, 2])
+        net.init_model("he_fout")
+        net.to(dev).eval()
+        net.set_active_subnet(ks=7, e=6, d=2, pixel_d=2)                     # eval_ofa_net_sr.py:207-220
+        self.net = net
+        self.n_params = sum(p.numel() for p in net.parameters())
+        utils = importlib.import_module(PKG + ".utils")
+        g = torch.Generator(device="cpu").manual_seed(4321)
+        lrs = [torch.rand((1, 3, h // 4, w // 4), generator=g) for (h, w) in SET14_HR]
+        self.buckets = [torch.cat(b).to(dev) for b in utils.bucket_by_size(lrs)]
+        self.n_images = len(lrs)
+
+    def step(self, i):
+        torch = self.torch
+        outs = []
+        with torch.no_grad():
+            for lr in self.buckets:
+                if self.act_dtype == torch.float32:
+                    outs.append(self.net(lr))
+                else:
+                    with torch.autocast("cuda", dtype=self.act_dtype):
+                        outs.append(self.net(lr))
+        return outs
+
+
+def timed(fn, warmup, steps, fence):
+    for i in range(warmup):
+        fn(i)
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = train_step(args.warmup + i)
+    last = None
+    for i in range(steps):
+        last = fn(warmup + i)
     fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = 1e3 * dt / args.steps
-    value = world * N * args.steps / dt
-    final_loss = float(loss.detach())
+    return time.perf_counter() - t0, last
 
-    # ---- roofline of the dominant HIP kernel: events on the launch stream around every library launch
-    roofline = None
-    kernel_table = None
-    if not args.no_roofline:   # every rank runs the instrumented steps (they contain the gradient all-reduce); rank 0 reports
-        # per-kernel timing needs one API call per kernel: the instrumented steps run the per-op Functions
-        # (same kernels, same order) instead of the composite MB-block call used in the timed region
-        ops.FUSED_BLOCK = False
-        train_step(args.warmup + args.steps)
-        ops.TIMER = ops.KernelTimer()
-        nprof = min(args.steps, 6)
+
+def profile_steps(M, fn, first, nprof):
+    """run `nprof` more steps with every library launch bracketed by events on its own stream; returns
+    {symbol: {launches, total_us, bytes, flops}} (include/ofasr.h, Diagnostics)."""
+    C = M["_C"]
+    fn(first)                      # settle allocations made by the first profiled launch sites
+    C.lib().ofasr_profile_enable(1)
+    try:
         for i in range(nprof):
-            train_step(args.warmup + args.steps + 1 + i)
-        summ = ops.TIMER.summary()
-        ops.TIMER = None
-        ops.FUSED_BLOCK = True
-        kernel_table = {k: {"avg_us": round(v["avg_us"], 2), "launches_per_step": v["launches"] / nprof,
-                            "ms_per_step": round(v["total_ms"] / nprof, 4),
-                            "GBps": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["total_ms"] > 0 else None}
-                        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])}
-        # group API calls that are ONE kernel launch by the HIP kernel they run; the dominant one is reported
-        groups = {}
-        for k, v in summ.items():
-            sym = kernel_symbol(k)
-            if sym is None:
-                continue
-            g = groups.setdefault(sym, {"launches": 0, "total_ms": 0.0, "bytes": 0.0, "flops": 0.0, "calls": []})
-            for f in ("launches", "total_ms", "bytes", "flops"):
-                g[f] += v[f]
-            g["calls"].append(k)
-        name, top = max(groups.items(), key=lambda kv: kv[1]["total_ms"])
-        achieved = top["bytes"] / (top["total_ms"] * 1e-3) / 1e9
-        per_launch = top["bytes"] / top["launches"]
-        roofline = {"kernel": name, "api_calls": sorted(top["calls"]), "bound": "hbm", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic(name), "avg_launch_us": round(1e3 * top["total_ms"] / top["launches"], 2),
-                    "launches_per_step": top["launches"] / nprof,
-                    "algorithmic_bytes_per_launch": per_launch,
-                    "mfma_tflops": round(top["flops"] / (top["total_ms"] * 1e-3) / 1e12, 2),
-                    "hip_library_ms_per_step": round(sum(v["total_ms"] for v in summ.values()) / nprof, 3)}
-
-    # ---- CPU baseline: the oracle port of the same training step on the host cores (bounded sample)
-    cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(args, S)
-
-    if rank == 0:
-        line = {
-            "metric": "sr_training_images_per_sec_4x_64to256", "value": round(value, 2), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {"workload": "OFA-SR S4 supernet 4x progressive shrinking (elastic kernel {3,5,7}, e=6, d=4, "
-                                   "pd=2), LR %dx%d -> HR %dx%d, fwd+bwd+Adam, train-mode BN" % (S, S, 4 * S, 4 * S),
-                       "per_gpu_batch": N, "global_batch": N * world, "params": n_params,
-                       "kernel_transform_mode": 1, "compat_reference_indexing": True,
-                       "parallelism": "dp%d" % world, "grad_allreduce_bytes": n_params * 4 if world > 1 else 0,
-                       "final_loss": final_loss},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernel_table,
-        }
-        print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+            fn(first + 1 + i)
+    finally:
+        C.lib().ofasr_profile_enable(0)
+    return C.profile_read()
 
 
-def kernel_symbol(call):
-    """HIP kernel run by a single-launch API call of the timer table (None for multi-kernel calls)."""
-    if call.startswith("pwconv_fwd_") or call.startswith("pwconv_dgrad_"):
-        k_red, m_out = (int(v) for v in call.split("_")[2].split("to"))      # reduction width, output rows
-        if k_red <= 64:   # 16-bit aligned path: whole 128-row slabs of a 64-wide reduction take the slab-walk kernel
-            return "pw_fanout_slabs_kernel" if (k_red == 64 and m_out % 128 == 0 and m_out > 128) else "pw_fanout_kernel"
-        return "pw_fanin_pipe_kernel"
-    if call.startswith("dwconv_fwd_k") or call.startswith("dwconv_dgrad_k"):
-        return "dw_vec_kernel<K=%s>" % call.rsplit("k", 1)[1]
-    return {"pixel_shuffle": "ps_r2_kernel", "pixel_unshuffle": "ps_r2_kernel"}.get(call)
+def roofline_from(summ, nprof, dtype):
+    table = {}
+    for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_us"]):
+        if v["launches"] <= 0:
+            continue
+        secs = v["total_us"] * 1e-6
+        table[k] = {"avg_us": round(v["total_us"] / v["launches"], 2), "launches_per_step": round(v["launches"] / nprof, 2),
+                    "ms_per_step": round(v["total_us"] * 1e-3 / nprof, 4),
+                    "GBps": round(v["bytes"] / secs / 1e9, 1) if v["bytes"] > 0 else None,
+                    "TFLOPs": round(v["flops"] / secs / 1e12, 1) if v["flops"] > 0 else None}
+    cands = {k: v for k, v in summ.items() if v["launches"] > 0 and v["bytes"] > 0}
+    if not cands:
+        return None, table, None
+    name, top = max(cands.items(), key=lambda kv: kv[1]["total_us"])
+    secs = top["total_us"] * 1e-6
+    mfma_bound = name.startswith("conv_igemm") or name.startswith("conv_wgrad_kernel")
+    peak_tf = MFMA_PEAK_TF[dtype]
+    traffic, source = pmc_traffic(name)
+    if mfma_bound:
+        ach = top["flops"] / secs / 1e12
+        roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 1), "peak": peak_tf, "unit": "TFLOP/s",
+                "frac": round(ach / peak_tf, 4)}
+    else:
+        ach = top["bytes"] / secs / 1e9
+        roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4)}
+    roof.update({"traffic": traffic, "traffic_source": source,
+                 "avg_launch_us": round(top["total_us"] / top["launches"], 2),
+                 "launches_per_step": round(top["launches"] / nprof, 2),
+                 "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
+                 "hbm_gbps": round(top["bytes"] / secs / 1e9, 1),
+                 "mfma_tflops": round(top["flops"] / secs / 1e12, 2) if top["flops"] > 0 else None,
+                 "timing": "HIP events on the launch stream, composite path, %d profiled steps" % nprof,
+                 "hip_library_ms_per_step": round(sum(v["total_us"] for v in summ.values()) * 1e-3 / nprof, 3)})
+    # the 1x1 path (north_star: >= 70 % of the fp16/bf16 MFMA roofline is quoted against this)
+    pw = [v for k, v in summ.items() if k.startswith("pw_") and v["flops"] > 0]
+    pointwise = None
+    if pw:
+        t = sum(v["total_us"] for v in pw) * 1e-6
+        fl, by = sum(v["flops"] for v in pw), sum(v["bytes"] for v in pw)
+        pointwise = {"kernels": "pw_* (expand / project forward, input and weight gradients)",
+                     "mfma_tflops": round(fl / t / 1e12, 1), "frac_mfma": round(fl / t / 1e12 / peak_tf, 4),
+                     "hbm_gbps": round(by / t / 1e9, 1), "frac_hbm": round(by / t / 1e9 / HBM_PEAK_GBS, 4),
+                     "algorithmic_intensity_flop_per_byte": round(fl / by, 1),
+                     "ms_per_step": round(t * 1e3 / nprof, 3)}
+    return roof, table, pointwise
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
-    MI355X_MICROARCH.md prescribes) -- produced by tools/pmc_traffic.py into profiles/pmc_traffic.json."""
+    """HBM bytes per launch of `kernel` from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
+    corrected as MI355X_MICROARCH.md prescribes) -- tools/pmc_traffic.py writes profiles/pmc_traffic.json, keyed by the
+    kernel symbol; a static file refreshed with the profiles, NOT measured by this run."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             table = json.load(f)
     except Exception:
-        return None
-    base = kernel.split("<")[0]
-    hit = table.get(kernel) or table.get(base)
-    return None if hit is None else hit.get("hbm_bytes_per_launch")
+        return None, None
+    hit = table.get(kernel)
+    if hit is None:
+        return None, None
+    return hit.get("hbm_bytes_per_launch"), "profiles/pmc_traffic.json (rocprofv3 --pmc passes of the same command)"
 
 
 def run_cpu_baseline(args, S):
-    """time the CPU oracle port (oracle/s4_port.py, kind "port") of the same training step: same net,
-    same sub-network seeds, fp32, Adam -- on `cores` host threads, `cpu_images` images per step."""
+    """time the CPU oracle port (oracle/s4_port.py, kind "port") of the c3 training step: same net, same sub-network
+    seeds, fp32, Adam -- on `cores` host threads, `cpu_images` images per step."""
     import torch
     import torch.nn.functional as F
     from oracle import s4_port
@@ -278,8 +305,112 @@ def run_cpu_baseline(args, S):
         step(1 + i)
     dt = time.perf_counter() - t0
     return {"value": round(n * args.cpu_steps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d steps x %d images (same net/shapes/seeds as the GPU step, fp32, torch-CPU oracle port)"
+            "sample": "%d steps x %d images (same net/shapes/seeds as the GPU c3 step, fp32, torch-CPU oracle port)"
                       % (args.cpu_steps, n)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)   # rehearsal: ranks may share a GPU
+            dist.init_process_group(args.backend)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    torch.backends.cudnn.benchmark = True                           # sr_run_manager.py:153 (MIOpen find mode)
+
+    M = mods()
+    M["_C"].lib()   # fail loudly if the HIP extension is missing
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    S = args.lr_size or (48 if args.config == "c2" else 64)
+    if args.config == "c5":
+        wl = EvalWorkload(M, dev, args.dtype)
+        per_step = wl.n_images
+    else:
+        wl = TrainWorkload(M, args.config, dev, args.batch, S, args.dtype, world, rank, args.h2d)
+        per_step = args.batch
+    dt, last = timed(wl.step, args.warmup, args.steps, fence)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * per_step * args.steps / dt
+    final_loss = float(last.detach()) if args.config != "c5" else None
+
+    roofline = kernel_table = pointwise = None
+    if not args.no_roofline:   # every rank runs the profiled steps (they contain the gradient all-reduce); rank 0 reports
+        nprof = min(args.steps, 6)
+        summ = profile_steps(M, wl.step, args.warmup + args.steps, nprof)
+        roofline, kernel_table, pointwise = roofline_from(summ, nprof, args.dtype)
+
+    fp32 = None
+    if args.config == "c3" and args.dtype != "f32" and not args.no_fp32:
+        # the reference computes in fp32: the same step with fp32 activations, a short leg of its own
+        del wl
+        torch.cuda.empty_cache()
+        wl32 = TrainWorkload(M, "c3", dev, args.batch, S, "f32", world, rank, False)
+        dt32, l32 = timed(wl32.step, 3, args.fp32_steps, fence)
+        if world > 1:
+            t = torch.tensor([dt32], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt32 = float(t.item())
+        fp32 = {"value": round(world * args.batch * args.fp32_steps / dt32, 2), "unit": "images/s",
+                "ms_per_step": round(1e3 * dt32 / args.fp32_steps, 3), "steps": args.fp32_steps, "warmup": 3,
+                "dtype": "f32", "final_loss": float(l32.detach())}
+        del wl32
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "c3":
+        cpu_baseline = run_cpu_baseline(args, S)
+
+    if rank == 0:
+        if args.config == "c3":
+            metric = "sr_training_images_per_sec_4x_64to256"
+            workload = ("OFA-SR S4 supernet 4x progressive shrinking (elastic kernel {3,5,7}, e=6, d=4, pd=2), "
+                        "LR %dx%d -> HR %dx%d, fwd+bwd+Adam, train-mode BN" % (S, S, 4 * S, 4 * S))
+        elif args.config == "c2":
+            metric = "sr_training_images_per_sec_2x_48to96"
+            workload = ("OFA-SR S4 supernet 2x, fixed sub-network k=3 / d=4 / e=6, LR %dx%d -> HR %dx%d, fwd+bwd+Adam, "
+                        "train-mode BN (BASELINE config 2)" % (S, S, 2 * S, 2 * S))
+        else:
+            metric = "sr_inference_images_per_sec_4x_set14_sizes"
+            workload = ("sampled sub-network (ks=7, e=6, d=2, pixel_d=2) 4x inference over the 14 Set14 image sizes "
+                        "(LR 62x90 .. 192x128), eval-mode BN, equal sizes batched: %d forward calls per pass "
+                        "(BASELINE config 5)" % len(wl.buckets))
+        cfg = {"workload": workload, "params": wl.n_params if args.config == "c5" else None,
+               "kernel_transform_mode": 1, "compat_reference_indexing": True, "parallelism": "dp%d" % world}
+        if args.config != "c5":
+            cfg.update({"per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                        "grad_allreduce_bytes": 2160422 * 4 if world > 1 else 0, "final_loss": final_loss})
+            cfg.pop("params")
+        else:
+            cfg["images_per_pass"] = per_step
+        line = {
+            "metric": metric, "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic", "config": cfg, "roofline": roofline, "pointwise": pointwise, "fp32": fp32,
+            "cpu_baseline": cpu_baseline, "kernels": kernel_table,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

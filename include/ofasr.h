@@ -11,9 +11,16 @@
  * Conventions
  *   - plain C: device pointers + sizes, no torch types; every call is asynchronous on `stream`
  *     (a hipStream_t passed as void*; NULL = the null stream).
- *   - returns OFASR_OK (0) or a negative ofasr_status; never throws, never allocates, never
- *     synchronises; no global mutable state except a thread-local last-error string.
- *     Safe to call from several host threads on different streams, and inside hipGraph capture.
+ *   - returns OFASR_OK (0) or a negative ofasr_status; never throws, never allocates device
+ *     memory, never synchronises (the one exception is the measurement call ofasr_profile_read).
+ *   - process-wide state, all of it behind mutexes / atomics: the thread-local last-error string;
+ *     the per-kernel launch counters and the optional event profile (section "Diagnostics");
+ *     and, used only by ofasr_mbconv_bwd, ONE side stream with its fork/join events, the list of
+ *     unjoined deferred calls and the ofasr_mbconv_defer_join switch (one process drives one GPU:
+ *     two host threads calling ofasr_mbconv_bwd on two streams share that side stream and its
+ *     pending list -- correct, since every call orders itself by events, but not independent).
+ *     Every other entry point is re-entrant: safe from several host threads on different
+ *     streams, and inside hipGraph capture.
  *   - activations are NCHW-contiguous, `dtype` selects their element type (f32 / f16 / bf16);
  *     weights / filters / gradients of weights are ALWAYS fp32 (master weights), accumulation
  *     is fp32.  16-bit activation paths round once, on store.
@@ -242,6 +249,24 @@ int ofasr_conv2d_dgrad(const void* dy, const float* w, void* dx, int64_t N, int6
 size_t ofasr_conv2d_wgrad_workspace(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K);
 int ofasr_conv2d_wgrad(const void* dy, const void* x, float* dw, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
                        int64_t W, int K, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Diagnostics (tests and bench.py; nothing on the product path calls these).
+ *   Every kernel launch of the library is counted per kernel symbol (template arguments resolved, e.g.
+ *   "dw_mfma_kernel<ofasr::bf16_t, 7, false, true, true>"): ofasr_debug_launch_count(substr) sums the counters of
+ *   the symbols containing `substr` (NULL / "" = all) since the last ofasr_debug_reset_launch_counts(), so a parity
+ *   test can assert WHICH kernel variant served a call; ofasr_debug_launch_table() lists "count<TAB>symbol" lines.
+ *   ofasr_profile_enable(1) brackets every following launch with two events recorded on the stream the kernel is
+ *   launched on (the caller's or the library's side stream); ofasr_profile_read() waits for them -- the library's only
+ *   synchronising call -- and returns "symbol<TAB>launches<TAB>total_us<TAB>algorithmic_bytes<TAB>flops" lines for the
+ *   launches bracketed since the previous read (bytes / flops per DESIGN.md section 3; 0 where not annotated).
+ *   Returned strings stay valid until the next call of the same function.
+ * ------------------------------------------------------------------------------------------- */
+long long ofasr_debug_launch_count(const char* substr);
+void ofasr_debug_reset_launch_counts(void);
+const char* ofasr_debug_launch_table(void);
+int ofasr_profile_enable(int on);
+const char* ofasr_profile_read(void);
 
 #ifdef __cplusplus
 }

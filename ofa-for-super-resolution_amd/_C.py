@@ -75,7 +75,39 @@ SIGNATURES = {
     "ofasr_mbconv_defer_join": (_c_int, [_c_int]),
     "ofasr_mbconv_join": (_c_int, [_c_vp]),
     "ofasr_side_stream": (_c_vp, []),
+    "ofasr_debug_launch_count": (ctypes.c_longlong, [ctypes.c_char_p]),
+    "ofasr_debug_reset_launch_counts": (None, []),
+    "ofasr_debug_launch_table": (ctypes.c_char_p, []),
+    "ofasr_profile_enable": (_c_int, [_c_int]),
+    "ofasr_profile_read": (ctypes.c_char_p, []),
 }
+
+
+def launch_count(substr=""):
+    """launches of the kernels whose symbol contains `substr` since the last reset (include/ofasr.h, Diagnostics)."""
+    return int(lib().ofasr_debug_launch_count(substr.encode()))
+
+
+def reset_launch_counts():
+    lib().ofasr_debug_reset_launch_counts()
+
+
+def launch_table():
+    out = {}
+    for line in lib().ofasr_debug_launch_table().decode().splitlines():
+        n, name = line.split("\t", 1)
+        if int(n):
+            out[name] = int(n)
+    return out
+
+
+def profile_read():
+    """{kernel symbol: {launches, total_us, bytes, flops}} of the launches bracketed since the last read."""
+    out = {}
+    for line in lib().ofasr_profile_read().decode().splitlines():
+        name, n, us, by, fl = line.rsplit("\t", 4)
+        out[name] = {"launches": float(n), "total_us": float(us), "bytes": float(by), "flops": float(fl)}
+    return out
 
 
 class MBConvDesc(ctypes.Structure):

@@ -497,10 +497,11 @@ OFASR_EXPORT int ofasr_bn_stats(const void* x, int64_t N, int64_t C, int64_t HW,
     dim3 grid((unsigned)C, (unsigned)P);
     hipStream_t st = as_stream(stream);
     const bool v = vec_ok(HW, dtype, x, nullptr, nullptr, nullptr);
+    prof_note((dtype == OFASR_F32 ? 4.0 : 2.0) * (double)N * (double)C * (double)HW, 0.0);
     OFASR_BN_DISPATCH_T(dtype, {
-        if (v) hipLaunchKernelGGL((bn_stats_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)x,
+        if (v) OFASR_LAUNCH((bn_stats_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)x,
                                   (double*)workspace, (int)N, (int)C, (int)HW, P);
-        else hipLaunchKernelGGL((bn_stats_kernel<T, false>), grid, dim3(BN_THREADS), 0, st, (const T*)x,
+        else OFASR_LAUNCH((bn_stats_kernel<T, false>), grid, dim3(BN_THREADS), 0, st, (const T*)x,
                                 (double*)workspace, (int)N, (int)C, (int)HW, P);
     });
     return check_launch(name);
@@ -514,7 +515,7 @@ OFASR_EXPORT int ofasr_bn_finalize(const void* workspace, int64_t n_partials, in
     OFASR_REQUIRE(C > 0 && mean && invstd && scale && shift, OFASR_ERR_INVALID_ARG, "%s: null output or C<=0", name);
     OFASR_REQUIRE(training ? (workspace != nullptr && n_partials > 0 && count > 0) : (running_mean && running_var),
                   OFASR_ERR_INVALID_ARG, "%s: missing statistics source", name);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, as_stream(stream),
+    OFASR_LAUNCH(bn_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, as_stream(stream),
                        (const double*)workspace, (int)n_partials, (int)C, count, gamma, beta, running_mean, running_var,
                        momentum, eps, training, mean, invstd, scale, shift);
     return check_launch(name);
@@ -609,7 +610,7 @@ int bn_finalize_cp(const float2* partial, int64_t P, int64_t C, double count, co
     OFASR_REQUIRE(C > 0 && mean && invstd && scale && shift, OFASR_ERR_INVALID_ARG, "%s: null output or C<=0", name);
     OFASR_REQUIRE(training ? (partial != nullptr && P > 0 && count > 0) : (running_mean && running_var),
                   OFASR_ERR_INVALID_ARG, "%s: missing statistics source", name);
-    hipLaunchKernelGGL(bn_finalize_cp_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(stream), partial, (int)P, (int)C,
+    OFASR_LAUNCH(bn_finalize_cp_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(stream), partial, (int)P, (int)C,
                        count, gamma, beta, running_mean, running_var, momentum, eps, training, mean, invstd, scale, shift,
                        k0, k1, k2);
     return check_launch(name);
@@ -623,7 +624,7 @@ int bn_finalize_bump(const void* workspace, int64_t n_partials, int64_t C, doubl
     OFASR_REQUIRE(C > 0 && mean && invstd && scale && shift, OFASR_ERR_INVALID_ARG, "%s: null output or C<=0", name);
     OFASR_REQUIRE(training ? (workspace != nullptr && n_partials > 0 && count > 0) : (running_mean && running_var),
                   OFASR_ERR_INVALID_ARG, "%s: missing statistics source", name);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, as_stream(stream),
+    OFASR_LAUNCH(bn_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, as_stream(stream),
                        (const double*)workspace, (int)n_partials, (int)C, count, gamma, beta, running_mean, running_var,
                        momentum, eps, training, mean, invstd, scale, shift, k0, k1, k2);
     return check_launch(name);
@@ -638,8 +639,9 @@ static int launch_bn_apply(const char* name, const void* x, const void* residual
     dim3 grid((unsigned)C, (unsigned)P);
     hipStream_t st = as_stream(stream);
     const bool v = vec_ok(HW, dtype, x, residual, y, nullptr);
+    prof_note((dtype == OFASR_F32 ? 4.0 : 2.0) * (double)N * (double)C * (double)HW * (residual ? 3.0 : 2.0), 0.0);
 #define OFASR_BNF(VEC, ACT, RES)                                                                                   \
-    hipLaunchKernelGGL((bn_act_fwd_kernel<T, VEC, ACT, RES>), grid, dim3(BN_THREADS), 0, st, (const T*)x,          \
+    OFASR_LAUNCH((bn_act_fwd_kernel<T, VEC, ACT, RES>), grid, dim3(BN_THREADS), 0, st, (const T*)x,          \
                        (const T*)residual, (T*)y, src, (int)N, (int)C, (int)HW, P)
     OFASR_BN_DISPATCH_T(dtype, {
         if (v) {
@@ -723,10 +725,10 @@ OFASR_EXPORT int ofasr_bn_act_bwd(const void* dy, const void* x, const void* res
     hipStream_t st = as_stream(stream);
     const bool v = vec_ok(HW, dtype, dy, x, residual, dx) && ((reinterpret_cast<uintptr_t>(dresidual) & 15) == 0);
 #define OFASR_BNR(VEC, ACT, RES)                                                                                     \
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, ACT, RES>), grid, dim3(BN_THREADS), 0, st, (const T*)dy,        \
+    OFASR_LAUNCH((bn_bwd_reduce_kernel<T, VEC, ACT, RES>), grid, dim3(BN_THREADS), 0, st, (const T*)dy,        \
                        (const T*)x, (const T*)residual, scale, shift, mean, invstd, partial, (int)N, (int)C, (int)HW, P)
 #define OFASR_BNA(VEC, ACT, RES)                                                                                     \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC, ACT, RES>), grid, dim3(BN_THREADS), 0, st, (const T*)dy,         \
+    OFASR_LAUNCH((bn_bwd_apply_kernel<T, VEC, ACT, RES>), grid, dim3(BN_THREADS), 0, st, (const T*)dy,         \
                        (const T*)x, (const T*)residual, (T*)dx, (T*)dresidual, scale, shift, mean, invstd,           \
                        (const double*)partial, P, M, training, dgamma, dbeta, (int)N, (int)C, (int)HW, P)
 #define OFASR_BN_BOTH(MACRO)                                                                              \
@@ -739,9 +741,12 @@ OFASR_EXPORT int ofasr_bn_act_bwd(const void* dy, const void* x, const void* res
             else { if (residual) MACRO(false, 0, true); else MACRO(false, 0, false); }                    \
         }                                                                                                 \
     })
+    const double tensor_bytes = (dtype == OFASR_F32 ? 4.0 : 2.0) * (double)N * (double)C * (double)HW;
+    prof_note(tensor_bytes * (residual ? 3.0 : 2.0), 0.0);                         // reads dy, x (, residual)
     OFASR_BN_BOTH(OFASR_BNR);
     rc = check_launch(name);
     if (rc) return rc;
+    prof_note(tensor_bytes * (3.0 + (residual ? 1.0 : 0.0) + (dresidual ? 1.0 : 0.0)), 0.0);   // + writes dx (, dresidual)
     OFASR_BN_BOTH(OFASR_BNA);
 #undef OFASR_BNR
 #undef OFASR_BNA

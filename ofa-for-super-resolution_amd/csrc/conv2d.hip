@@ -265,14 +265,16 @@ static int launch_conv2d(const char* name, const void* x, const float* w, void* 
                          int64_t H, int64_t W, int K, int dgrad, void* ws, hipStream_t st) {
     const CvPlan p = cv_plan(Cin, Cout, K, dgrad, N, H, W);
     const long long total = (long long)(p.img_bytes / 2);
-    hipLaunchKernelGGL((conv_prep_kernel<T>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, w, (T*)ws, (int)Cin, K,
+    OFASR_LAUNCH((conv_prep_kernel<T>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, w, (T*)ws, (int)Cin, K,
                        dgrad, p.M, p.Kdim, p.nrb, total);
     int rc = check_launch(name);
     if (rc) return rc;
     const int tiles_x = (int)cdiv(W, CV_TW), tiles_y = (int)cdiv(H, p.th);
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)N, (unsigned)p.nslab);
+    prof_note((double)sizeof(T) * (double)N * (double)H * (double)W * (double)(Cin + Cout),
+              2.0 * (double)N * (double)H * (double)W * (double)Cin * (double)Cout * K * K);
 #define OFASR_CV(KS, RB, WM, WP, ONEK)                                                                                  \
-    hipLaunchKernelGGL((conv_igemm_kernel<T, KS, RB, WM, WP, ONEK>), grid, dim3(64 * WM * WP), 0, st, (const T*)x,         \
+    OFASR_LAUNCH((conv_igemm_kernel<T, KS, RB, WM, WP, ONEK>), grid, dim3(64 * WM * WP), 0, st, (const T*)x,         \
                        (const T*)ws, (T*)y, p.Kdim, p.M, (int)H, (int)W, tiles_x, p.nkc, p.nrb)
 #define OFASR_CVK(KS, ONEK)                                                                                         \
     switch (p.cfg) {                                                                                                \
@@ -524,10 +526,13 @@ struct CvWgPlan {
     int rows, cib, rbw;
     CvWgParams P;
     size_t part_bytes;
+    double note_bytes, note_flops;   // algorithmic bytes (16-bit activations) / flops of the launch (profile table)
 };
 
 static CvWgPlan cv_wg_plan(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K) {
     CvWgPlan p{};
+    p.note_bytes = 2.0 * (double)N * (double)H * (double)W * (double)(Cin + Cout);
+    p.note_flops = 2.0 * (double)N * (double)H * (double)W * (double)Cin * (double)Cout * K * K;
     const bool wide = Cin > 32;
     const int rcls = Cout > 64 ? 0 : (Cout > 32 ? 1 : 2);
     p.cfg = (wide ? 0 : 3) + rcls;
@@ -554,14 +559,15 @@ static int launch_conv2d_wgrad(const char* name, const void* dy, const void* x, 
                                hipStream_t st) {
     const CvWgParams& P = p.P;
     dim3 grid((unsigned)P.ksplit, (unsigned)K, (unsigned)P.nz);
+    prof_note(p.note_bytes, p.note_flops);
 #define OFASR_WG(KS, RBW, WCO, WCI, WK)                                                                              \
     {                                                                                                                \
-        hipLaunchKernelGGL((conv_wgrad_kernel<T, KS, RBW, WCO, WCI, WK>), grid, dim3(256), 0, st, (const T*)dy,      \
+        OFASR_LAUNCH((conv_wgrad_kernel<T, KS, RBW, WCO, WCI, WK>), grid, dim3(256), 0, st, (const T*)dy,      \
                            (const T*)x, (float*)ws, P);                                                              \
         int rc = check_launch(name);                                                                                 \
         if (rc) return rc;                                                                                           \
         const long long tot = (long long)KS * P.nz * (WCO * WCI) * RBW * KS * 16 * 64;                               \
-        hipLaunchKernelGGL((conv_wgrad_reduce_kernel<KS, RBW, WCO, WCI>), dim3((unsigned)cdiv(tot, 256)),            \
+        OFASR_LAUNCH((conv_wgrad_reduce_kernel<KS, RBW, WCO, WCI>), dim3((unsigned)cdiv(tot, 256)),            \
                            dim3(256), 0, st, (const float*)ws, dw, P, tot);                                          \
     }
 #define OFASR_WGK(KS)                                                                                                \

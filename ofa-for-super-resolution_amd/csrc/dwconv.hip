@@ -845,6 +845,8 @@ template <typename T, bool FLIP, bool XF = false, bool STAT = false>
 static int launch_conv(const char* name, const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H,
                        int64_t W, int K, hipStream_t st, InputXf xf = InputXf{}, StatOut so = StatOut{nullptr, 0},
                        BnFold fold = BnFold{}) {
+    prof_note(2.0 * sizeof(T) * (double)N * (double)C * (double)H * (double)W + 4.0 * (double)C * K * K,
+              2.0 * K * K * (double)N * (double)C * (double)H * (double)W);
     if constexpr (sizeof(T) == 2) {
         if (mfma_geom_ok(H, W, K, x, y)) {
             VecGeom vg0;
@@ -855,11 +857,11 @@ static int launch_conv(const char* name, const void* x, const float* f, void* y,
             }
             const long long units = (long long)C * cdiv(N, DWM_NPW);
             if (K == 5)
-                hipLaunchKernelGGL((dw_mfma_kernel<T, 5, FLIP, XF, STAT>), dim3((unsigned)cdiv(units, DW_WAVES)),
+                OFASR_LAUNCH((dw_mfma_kernel<T, 5, FLIP, XF, STAT>), dim3((unsigned)cdiv(units, DW_WAVES)),
                                    dim3(64 * DW_WAVES), 0, st, (const T*)x, f, (T*)y, (int)N, (int)C, (int)H, (int)W, nslabs,
                                    xf, so, fold);
             else
-                hipLaunchKernelGGL((dw_mfma_kernel<T, 7, FLIP, XF, STAT>), dim3((unsigned)cdiv(units, DW_WAVES)),
+                OFASR_LAUNCH((dw_mfma_kernel<T, 7, FLIP, XF, STAT>), dim3((unsigned)cdiv(units, DW_WAVES)),
                                    dim3(64 * DW_WAVES), 0, st, (const T*)x, f, (T*)y, (int)N, (int)C, (int)H, (int)W, nslabs,
                                    xf, so, fold);
             return check_launch(name);
@@ -874,7 +876,7 @@ static int launch_conv(const char* name, const void* x, const float* f, void* y,
             set_error("%s: statistics slab count %d != %lld", name, so.P, (long long)(N * vg.nslabs));             \
             return OFASR_ERR_INVALID_ARG;                                                                          \
         }                                                                                                          \
-        hipLaunchKernelGGL((dw_vec_kernel<T, KK, FLIP, XF, STAT>), dim3((unsigned)cdiv(nwaves, DW_WAVES)),         \
+        OFASR_LAUNCH((dw_vec_kernel<T, KK, FLIP, XF, STAT>), dim3((unsigned)cdiv(nwaves, DW_WAVES)),         \
                            dim3(64 * DW_WAVES), 0, st, (const T*)x, f, (T*)y, (int)C, (int)H, (int)W, vg, nwaves,  \
                            xf, so, fold);                                                                          \
         return check_launch(name);                                                                                 \
@@ -897,7 +899,7 @@ static int launch_conv(const char* name, const void* x, const float* f, void* y,
     {                                                                                                        \
         const int nstrips = Strips<KK>::count((int)W);                                                       \
         const long long units = (long long)N * C * nstrips * nchunks;                                        \
-        hipLaunchKernelGGL((dw_strip_kernel<T, KK, FLIP>), dim3((unsigned)cdiv(units, DW_WAVES)),            \
+        OFASR_LAUNCH((dw_strip_kernel<T, KK, FLIP>), dim3((unsigned)cdiv(units, DW_WAVES)),            \
                            dim3(64 * DW_WAVES), 0, st, (const T*)x, f, (T*)y, (int)C, (int)H, (int)W, nstrips, \
                            nchunks, rows_per_chunk, units);                                                  \
     }
@@ -940,13 +942,15 @@ static int conv_entry(const char* name, const void* x, const float* f, void* y, 
 template <typename T, bool XF = false>
 static int launch_wgrad(const char* name, const void* dy, const void* x, float* df, int64_t N, int64_t C,
                         int64_t H, int64_t W, int K, float* ws, hipStream_t st, InputXf xf = InputXf{}) {
+    prof_note(2.0 * sizeof(T) * (double)N * (double)C * (double)H * (double)W + 4.0 * (double)C * K * K,
+              2.0 * K * K * (double)N * (double)C * (double)H * (double)W);
     {
         VecGeom vg;
         if (vec_geom(H, W, (int)sizeof(T), 4, dy, x, vg)) {
             const long long nwaves = (long long)N * C * vg.nslabs;
             const unsigned grid = (unsigned)cdiv(nwaves, DW_WAVES);
 #define OFASR_DWWV(KK)                                                                                              \
-    hipLaunchKernelGGL((dw_wgrad_vec_kernel<T, KK, XF>), dim3(grid), dim3(64 * DW_WAVES), 0, st, (const T*)dy,      \
+    OFASR_LAUNCH((dw_wgrad_vec_kernel<T, KK, XF>), dim3(grid), dim3(64 * DW_WAVES), 0, st, (const T*)dy,      \
                        (const T*)x, ws, (int)H, (int)W, vg, nwaves, (int)C, xf)
             switch (K) {
                 case 1: OFASR_DWWV(1); break;
@@ -958,7 +962,7 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
             int rc0 = check_launch(name);
             if (rc0) return rc0;
             const long long CKK0 = (long long)C * K * K;
-            hipLaunchKernelGGL(dw_wgrad_vec_reduce_kernel, dim3((unsigned)cdiv(CKK0, 256)), dim3(256), 0, st, ws, df,
+            OFASR_LAUNCH(dw_wgrad_vec_reduce_kernel, dim3((unsigned)cdiv(CKK0, 256)), dim3(256), 0, st, ws, df,
                                (int)N, (int)C, vg.nslabs, K * K);
             return check_launch(name);
         }
@@ -970,7 +974,7 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
     const int nparts = wgrad_parts(N, C);
     const long long units = (long long)C * nparts;
 #define OFASR_DW_WG(KK)                                                                                        \
-    hipLaunchKernelGGL((dw_wgrad_kernel<T, KK>), dim3((unsigned)cdiv(units, DW_WAVES)), dim3(64 * DW_WAVES), 0, \
+    OFASR_LAUNCH((dw_wgrad_kernel<T, KK>), dim3((unsigned)cdiv(units, DW_WAVES)), dim3(64 * DW_WAVES), 0, \
                        st, (const T*)dy, (const T*)x, ws, (int)N, (int)C, (int)H, (int)W,                      \
                        Strips<KK>::count((int)W), nparts, units)
     switch (K) {
@@ -983,7 +987,7 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
     int rc = check_launch(name);
     if (rc) return rc;
     const long long CKK = (long long)C * K * K;
-    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)cdiv(CKK, 256)), dim3(256), 0, st, ws, df, nparts,
+    OFASR_LAUNCH(dw_wgrad_reduce_kernel, dim3((unsigned)cdiv(CKK, 256)), dim3(256), 0, st, ws, df, nparts,
                        CKK);
     return check_launch(name);
 }

@@ -179,7 +179,7 @@ OFASR_EXPORT int ofasr_ktransform_fwd(const float* w_max, const int* ks, int nst
     if (rc) return rc;
     OFASR_REQUIRE(w_max && f, OFASR_ERR_INVALID_ARG, "ofasr_ktransform_fwd: null pointer");
     if (C == 0) return OFASR_OK;
-    hipLaunchKernelGGL(kt_fwd_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(stream), w_max, f, p);
+    OFASR_LAUNCH(kt_fwd_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(stream), w_max, f, p);
     return check_launch("ofasr_ktransform_fwd");
 }
 
@@ -213,7 +213,7 @@ OFASR_EXPORT int ofasr_ktransform_bwd(const float* w_max, const int* ks, int nst
         }
     }
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(kt_bwd_chain_kernel, dim3((unsigned)C), dim3(64), 0, st, w_max, df, dw_max,
+    OFASR_LAUNCH(kt_bwd_chain_kernel, dim3((unsigned)C), dim3(64), 0, st, w_max, df, dw_max,
                        (float*)workspace, p, (int)C);
     rc = check_launch(name);
     if (rc || !chain) return rc;
@@ -221,7 +221,7 @@ OFASR_EXPORT int ofasr_ktransform_bwd(const float* w_max, const int* ks, int nst
         const int q = ks[s + 1] * ks[s + 1];
         const float* G = (const float*)workspace + p.ws_off[s];
         const float* CR = G + (int64_t)C * q;
-        hipLaunchKernelGGL(kt_bwd_mat_kernel, dim3((unsigned)cdiv((int64_t)q * q, 16)), dim3(256), 0, st, G, CR,
+        OFASR_LAUNCH(kt_bwd_mat_kernel, dim3((unsigned)cdiv((int64_t)q * q, 16)), dim3(256), 0, st, G, CR,
                            p.dmats[s], q, (int)C);
         rc = check_launch(name);
         if (rc) return rc;

@@ -222,7 +222,7 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
     const bool fused = fuse_apply(d, s, act_buf);
     if (!fused && ((d->bn_training[0] && d->num_batches_tracked[0]) || (d->bn_training[1] && d->num_batches_tracked[1]) ||
                    (d->bn_training[2] && d->num_batches_tracked[2]))) {
-        hipLaunchKernelGGL(bump_counters_kernel, dim3(1), dim3(64), 0, as_stream(stream),
+        OFASR_LAUNCH(bump_counters_kernel, dim3(1), dim3(64), 0, as_stream(stream),
                            d->bn_training[0] ? d->num_batches_tracked[0] : nullptr,
                            d->bn_training[1] ? d->num_batches_tracked[1] : nullptr,
                            d->bn_training[2] ? d->num_batches_tracked[2] : nullptr);

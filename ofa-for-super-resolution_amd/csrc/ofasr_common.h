@@ -22,6 +22,39 @@ inline int check_launch(const char* what) {
     return OFASR_OK;
 }
 
+// ---- launch bookkeeping ------------------------------------------------------------------------
+// Every kernel launch of the library goes through OFASR_LAUNCH.  Each launch site template instance owns a
+// LaunchSite (its name is the fully resolved, demangled kernel symbol the runtime reports for the host stub -- the
+// name rocprofv3 prints, minus the parameter list) with a launch counter --
+// tests assert the routing of a call through it (ofasr_debug_launch_count) -- and, while profiling is switched on
+// (ofasr_profile_enable), the launch is bracketed by two events recorded on the stream it is launched on, so
+// bench.py's per-kernel table and `roofline` describe the kernels the timed step really ran, whichever stream
+// (caller's or the library's side stream) they ran on.  prof_note() attaches algorithmic bytes / flops to the next
+// launch of this host thread.  With profiling off the cost per launch is one relaxed increment.
+struct LaunchSite {
+    const char* name;
+    unsigned long long count;
+    LaunchSite* next;
+};
+LaunchSite* register_site(const void* host_fn, const char* fallback);
+template <auto F> inline LaunchSite* launch_site(const char* spelled) {
+    static LaunchSite* s = register_site(reinterpret_cast<const void*>(F), spelled);
+    return s;
+}
+extern int g_profile_on;
+void prof_note(double bytes, double flops);
+void* prof_begin(LaunchSite* s, hipStream_t st);
+void prof_end(void* rec, hipStream_t st);
+
+#define OFASR_LAUNCH(kernel, grid, block, shmem, stream, ...)                                \
+    do {                                                                                     \
+        ::ofasr::LaunchSite* _site = ::ofasr::launch_site<&kernel>(#kernel);                 \
+        __atomic_fetch_add(&_site->count, 1ull, __ATOMIC_RELAXED);                           \
+        void* _rec = ::ofasr::g_profile_on ? ::ofasr::prof_begin(_site, (stream)) : nullptr; \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                 \
+        if (_rec) ::ofasr::prof_end(_rec, (stream));                                         \
+    } while (0)
+
 #define OFASR_REQUIRE(cond, code, ...)      \
     do {                                    \
         if (!(cond)) {                      \

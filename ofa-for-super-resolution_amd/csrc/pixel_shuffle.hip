@@ -112,6 +112,7 @@ static int launch(const void* x, void* y, int64_t N, int64_t C, int64_t H, int64
                   "%s: dimension too large", name);
     const int64_t total = N * C * r * r * H * W;
     if (total == 0) return OFASR_OK;
+    prof_note(2.0 * (double)total * es, 0.0);
     const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
     if (r == 2 && (es == 2 || es == 4) && aligned && (W * es) % 16 == 0) {
         const int Wq = (int)(W * es / 16);
@@ -119,17 +120,17 @@ static int launch(const void* x, void* y, int64_t N, int64_t C, int64_t H, int64
         const int64_t blocks = cdiv(items, 256);
         const int grid = (int)(blocks < 65536 ? blocks : 65536);
         if (es == 4)
-            hipLaunchKernelGGL((ps_r2_kernel<4, SHUFFLE>), dim3(grid), dim3(256), 0, st, (const uint4*)x,
+            OFASR_LAUNCH((ps_r2_kernel<4, SHUFFLE>), dim3(grid), dim3(256), 0, st, (const uint4*)x,
                                (uint4*)y, items, (int)H, Wq);
         else
-            hipLaunchKernelGGL((ps_r2_kernel<2, SHUFFLE>), dim3(grid), dim3(256), 0, st, (const uint4*)x,
+            OFASR_LAUNCH((ps_r2_kernel<2, SHUFFLE>), dim3(grid), dim3(256), 0, st, (const uint4*)x,
                                (uint4*)y, items, (int)H, Wq);
         return check_launch(name);
     }
     const int64_t blocks = cdiv(total, 256);
     const int grid = (int)(blocks < 65536 ? blocks : 65536);
 #define OFASR_PS_GENERIC(ES)                                                                       \
-    hipLaunchKernelGGL((ps_generic_kernel<typename uint_of<ES>::type, SHUFFLE>), dim3(grid), dim3(256), \
+    OFASR_LAUNCH((ps_generic_kernel<typename uint_of<ES>::type, SHUFFLE>), dim3(grid), dim3(256), \
                        0, st, (const typename uint_of<ES>::type*)x, (typename uint_of<ES>::type*)y,    \
                        total, (int)C, (int)H, (int)W, r)
     switch (es) {

@@ -1329,7 +1329,7 @@ static void launch_gemm_v(const void* x, WView wv, void* y, int64_t HW, int tile
                 HW % PW_TILE == 0) {
                 dim3 g1((unsigned)total_tiles);
 #define OFASR_FO_SLABS(NS, ST)                                                                                       \
-    hipLaunchKernelGGL((pw_fanout_slabs_kernel<T, NS, ST>), g1, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y, (int)HW, \
+    OFASR_LAUNCH((pw_fanout_slabs_kernel<T, NS, ST>), g1, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y, (int)HW, \
                        tiles_per_img, so)
                 if (nslab == 3) { if (so.partial) OFASR_FO_SLABS(3, true); else OFASR_FO_SLABS(3, false); }
                 else { if (so.partial) OFASR_FO_SLABS(2, true); else OFASR_FO_SLABS(2, false); }
@@ -1338,21 +1338,21 @@ static void launch_gemm_v(const void* x, WView wv, void* y, int64_t HW, int tile
             }
         }
         dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, FO_ROWS));
-        hipLaunchKernelGGL((pw_fanout_kernel<T, AL, WV, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
+        OFASR_LAUNCH((pw_fanout_kernel<T, AL, WV, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
                            (int)HW, tiles_per_img, xf, (const T*)addend, so);
     } else {
         dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, 64));
         if constexpr (Elem<T>::is16 && AL && WV) {
             static const bool fast_ok = [] { const char* e = getenv("OFASR_PW_FANIN_FAST"); return !(e && e[0] == '0'); }();
             if (fast_ok && wv.K % 4 == 0 && wv.M % 4 == 0)
-                hipLaunchKernelGGL((pw_fanin_pipe_kernel<T, XF, true>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv,
+                OFASR_LAUNCH((pw_fanin_pipe_kernel<T, XF, true>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv,
                                    (T*)y, (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf, (const T*)addend, so, fold);
             else
-                hipLaunchKernelGGL((pw_fanin_pipe_kernel<T, XF, false>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv,
+                OFASR_LAUNCH((pw_fanin_pipe_kernel<T, XF, false>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv,
                                    (T*)y, (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf, (const T*)addend, so, fold);
             return;
         }
-        hipLaunchKernelGGL((pw_fanin_kernel<T, AL, WV, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
+        OFASR_LAUNCH((pw_fanin_kernel<T, AL, WV, XF>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y,
                            (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf, (const T*)addend, so);
     }
 }
@@ -1370,6 +1370,10 @@ static int launch_gemm(const char* name, const void* x, WView wv, void* y, int64
     const int64_t total64 = N * tiles_per_img;
     OFASR_REQUIRE(total64 <= INT32_MAX, OFASR_ERR_UNSUPPORTED, "%s: too many pixel tiles", name);
     const int total_tiles = (int)total64;
+    {   // algorithmic bytes / flops of this launch: read K, write M channels of N*HW pixels
+        const double px = (double)N * (double)HW, es = (double)sizeof(T);
+        prof_note(es * px * (wv.K + wv.M + (addend ? wv.M : 0)) + 4.0 * wv.K * wv.M, 2.0 * px * wv.K * wv.M);
+    }
     if (so.partial)
         OFASR_REQUIRE(so.P == (wv.K <= 64 ? total_tiles : 2 * total_tiles), OFASR_ERR_INVALID_ARG,
                       "%s: statistics unit count %d does not match the launch", name, so.P);
@@ -1424,25 +1428,27 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
     // out(r, s): r indexes the big operand's channels
     const long long sr = big_is_dy ? ldw : 1, ss = big_is_dy ? 1 : ldw;
     const bool al = aligned_for(dy, x, HW, Elem<T>::is16);
+    prof_note((double)sizeof(T) * (double)N * (double)HW * (double)(Cin + Cout) + 4.0 * (double)Cin * (double)Cout,
+              2.0 * (double)N * (double)HW * (double)Cin * (double)Cout);
     if constexpr (Elem<T>::is16) {
         if (al) {
             const WdPlan wp = wd_plan(N, Cin, Cout, HW);
             dim3 grid((unsigned)wp.nsplit, (unsigned)cdiv(wp.MR, WD_ROWS), (unsigned)cdiv(wp.NS, WD_COLS));
             if constexpr (XF) {
                 if (big_is_dy)   // x is the S operand
-                    hipLaunchKernelGGL((pw_wgrad_direct_kernel<T, 2>), grid, dim3(512), 0, st, R, S, ws, wp.MR, wp.NS,
+                    OFASR_LAUNCH((pw_wgrad_direct_kernel<T, 2>), grid, dim3(512), 0, st, R, S, ws, wp.MR, wp.NS,
                                        (int)HW, wp, xf);
                 else
-                    hipLaunchKernelGGL((pw_wgrad_direct_kernel<T, 1>), grid, dim3(512), 0, st, R, S, ws, wp.MR, wp.NS,
+                    OFASR_LAUNCH((pw_wgrad_direct_kernel<T, 1>), grid, dim3(512), 0, st, R, S, ws, wp.MR, wp.NS,
                                        (int)HW, wp, xf);
             } else {
-                hipLaunchKernelGGL((pw_wgrad_direct_kernel<T>), grid, dim3(512), 0, st, R, S, ws, wp.MR, wp.NS, (int)HW,
+                OFASR_LAUNCH((pw_wgrad_direct_kernel<T>), grid, dim3(512), 0, st, R, S, ws, wp.MR, wp.NS, (int)HW,
                                    wp);
             }
             int rc = check_launch(name);
             if (rc) return rc;
             const long long tot = (long long)wp.MR * wp.NS;
-            hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(64 * WR_ZL), 0, st, ws, dw, wp.MR,
+            OFASR_LAUNCH(pw_wgrad_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(64 * WR_ZL), 0, st, ws, dw, wp.MR,
                                wp.NS, wp.nsplit, sr, ss);
             return check_launch(name);
         }
@@ -1453,15 +1459,15 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
     }
     dim3 grid((unsigned)cdiv(p.MR, 64), (unsigned)cdiv(p.NS, 64), (unsigned)p.nsplit);
     if (al)
-        hipLaunchKernelGGL((pw_wgrad_kernel<T, true>), grid, dim3(PW_THREADS), 0, st, R, S, ws, p.MR, p.NS, (int)HW,
+        OFASR_LAUNCH((pw_wgrad_kernel<T, true>), grid, dim3(PW_THREADS), 0, st, R, S, ws, p.MR, p.NS, (int)HW,
                            p.stages_per_img, p.total_stages, p.stages_per_split);
     else
-        hipLaunchKernelGGL((pw_wgrad_kernel<T, false>), grid, dim3(PW_THREADS), 0, st, R, S, ws, p.MR, p.NS, (int)HW,
+        OFASR_LAUNCH((pw_wgrad_kernel<T, false>), grid, dim3(PW_THREADS), 0, st, R, S, ws, p.MR, p.NS, (int)HW,
                            p.stages_per_img, p.total_stages, p.stages_per_split);
     int rc = check_launch(name);
     if (rc) return rc;
     const long long tot = (long long)p.MR * p.NS;
-    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(64 * WR_ZL), 0, st, ws, dw, p.MR, p.NS,
+    OFASR_LAUNCH(pw_wgrad_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(64 * WR_ZL), 0, st, ws, dw, p.MR, p.NS,
                        p.nsplit, sr, ss);
     return check_launch(name);
 }
