@@ -88,6 +88,12 @@ class OFAMobileNetS4(MobileNetS4):
     def _shuffle_depth(self):
         return self.runtime_depth[0] if self.COMPAT_REFERENCE_INDEXING else self.runtime_depth[_N_MB_STAGES]
 
+    def active_upscale(self):
+        """2 ** (number of conv+PixelShuffle blocks on the active path): the LR input a training / validation step
+        must feed.  Under COMPAT_REFERENCE_INDEXING this is NOT 2 ** pixel_d (quirk Q1: the shuffle stage reads
+        runtime_depth[0]), so callers ask the net instead of trusting the sampled pixel_d."""
+        return 2 ** len(self.block_group_info[_N_MB_STAGES][:self._shuffle_depth()])
+
     def active_block_sequence(self):
         """(kind, module) for every module on the active path, in execution order."""
         seq = [("stem", self.dec_first_conv_block)]

@@ -53,7 +53,11 @@ def validate(run_manager, epoch=0, is_test=True, image_size_list=None, width_mul
         run_manager.write_log("-" * 30 + " Validate %s " % name + "-" * 30, "train", should_print=False)
         dynamic_net.set_active_subnet(**setting)
         run_manager.write_log(dynamic_net.module_str, "train", should_print=False)
-        loss, psnr = run_manager.validate(epoch=epoch, is_test=is_test, run_str=name, net=dynamic_net)
+        # feed the LR image of the scale the active path really up-samples by (the reference always feeds the 2x image,
+        # quirk Q4, and under quirk Q1 pixel_d does not decide the scale)
+        up = dynamic_net.active_upscale() if hasattr(dynamic_net, "active_upscale") else None
+        kw = {} if up is None else {"input_key": "%dx_down_image" % up}
+        loss, psnr = run_manager.validate(epoch=epoch, is_test=is_test, run_str=name, net=dynamic_net, **kw)
         losses.append(loss)
         psnrs.append(psnr)
         valid_log += "%s (%.3f), " % (name, psnr)
@@ -69,8 +73,17 @@ def train_one_epoch(run_manager, args, epoch, warmup_epochs=0, warmup_lr=0):
     dynamic_net = run_manager.net
     dynamic_net.train()
     loader = run_manager.run_config.train_loader
+    sampler = getattr(loader, "sampler", None)
+    if hasattr(sampler, "set_epoch"):      # a rank-sharding sampler replays the same permutation otherwise
+        sampler.set_epoch(epoch)
     nBatch = len(loader)
     dev = run_manager.device
+    from ... import distributed as dd
+    if getattr(args, "independent_distributed_sampling", False) and dd.world_size() > 1:
+        # ranks drawing different sub-networks would disagree on which parameters get grad=None: FlatGradReducer
+        # decides that from the local touched set, so Adam state would diverge silently across ranks
+        raise ValueError("independent_distributed_sampling is not supported with data parallelism: every rank must "
+                         "train the same sub-network (shared seed rule, reference progressive_shrinking.py:164)")
     losses, psnr_meter, data_time = AverageMeter(), AverageMeter(), AverageMeter()
     loss_sum = torch.zeros((), device=dev, dtype=torch.float64)
     psnr_sum = torch.zeros((), device=dev, dtype=torch.float64)
@@ -107,7 +120,12 @@ def train_one_epoch(run_manager, args, epoch, warmup_epochs=0, warmup_lr=0):
             subnet_str += "%d: " % sub + ",".join(
                 "%s_%s" % (k, "%.1f" % subset_mean(v, 0) if isinstance(v, list) else v) for k, v in settings.items()
             ) + " || "
-            lr_img = x2 if settings["pixel_d"][0] == 1 else x4
+            # reference :177-180 picks the input by the sampled pixel_d; under quirk Q1 the S4 net up-samples by
+            # 2 ** (active shuffle blocks) whatever pixel_d says, so ask the net (same answer whenever they agree)
+            if hasattr(dynamic_net, "active_upscale"):
+                lr_img = x2 if dynamic_net.active_upscale() == 2 else x4
+            else:
+                lr_img = x2 if settings["pixel_d"][0] == 1 else x4
             with run_manager.autocast():
                 output = run_manager.net(lr_img)
             output = output.float()

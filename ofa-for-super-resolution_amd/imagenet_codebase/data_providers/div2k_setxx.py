@@ -13,14 +13,12 @@ torch.rand(1) < p, RandomRotation.get_params -> torch.empty(1).uniform_(lo, hi);
 Image.rotate(angle, NEAREST, expand=False), fill 0).  ModCrop / Scale / get_transform_L / the dataset / the
 samplers are plain PIL + torch in the reference too and are pinned by tests/golden/div2k.npz.
 """
-import math
 import os
 import warnings
 
 import numpy as np
 import torch
 import torch.utils.data
-from torch.utils.data.distributed import DistributedSampler
 
 try:   # PIL is optional at import time so that the GPU-side modules never depend on it
     from PIL import Image
@@ -177,25 +175,44 @@ class Div2K_SetXXDataset(torch.utils.data.Dataset):
         return {"image": to_tensor(H_img), "2x_down_image": to_tensor(L2_img), "4x_down_image": to_tensor(L4_img)}
 
 
-class MyDistributedSampler(DistributedSampler):
-    """DistributedSampler over a subset of indices (reference base_provider.py:106-131)"""
+class RankShardSampler(torch.utils.data.Sampler):
+    """One rank's share of an index set: a permutation seeded by the epoch (identical on every rank), padded by
+    wrapping to a multiple of the world size, then every `num_replicas`-th index starting at `rank` -- the
+    partition rule of the reference's MyDistributedSampler (base_provider.py:106-131) written as a plain Sampler.
+    Call set_epoch(e) before each epoch or every epoch replays the same order."""
 
-    def __init__(self, dataset, num_replicas=None, rank=None, sub_index_list=None):
-        super(MyDistributedSampler, self).__init__(dataset, num_replicas, rank)
-        self.sub_index_list = sub_index_list   # numpy
-        self.num_samples = int(math.ceil(len(self.sub_index_list) * 1.0 / self.num_replicas))
+    def __init__(self, indices, num_replicas, rank, shuffle=True):
+        self.indices = np.asarray(indices, dtype=np.int64)
+        self.num_replicas, self.rank, self.shuffle = int(num_replicas), int(rank), bool(shuffle)
+        if not 0 <= self.rank < self.num_replicas:
+            raise ValueError("rank %d outside a world of %d" % (self.rank, self.num_replicas))
+        self.num_samples = -(-len(self.indices) // self.num_replicas)
         self.total_size = self.num_samples * self.num_replicas
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        return self.num_samples
 
     def __iter__(self):
-        g = torch.Generator()
-        g.manual_seed(self.epoch)
-        indices = torch.randperm(len(self.sub_index_list), generator=g).tolist()
-        indices += indices[:(self.total_size - len(indices))]
-        indices = self.sub_index_list[indices].tolist()
-        assert len(indices) == self.total_size
-        indices = indices[self.rank:self.total_size:self.num_replicas]
-        assert len(indices) == self.num_samples
-        return iter(indices)
+        n = len(self.indices)
+        if self.shuffle:
+            order = torch.randperm(n, generator=torch.Generator().manual_seed(self.epoch)).numpy()
+        else:
+            order = np.arange(n)
+        order = np.concatenate([order, order[:self.total_size - n]])
+        return iter(self.indices[order[self.rank::self.num_replicas]].tolist())
+
+
+class MyDistributedSampler(RankShardSampler):
+    """the reference's constructor signature (dataset, num_replicas, rank, sub_index_list) on RankShardSampler"""
+
+    def __init__(self, dataset, num_replicas=None, rank=None, sub_index_list=None):
+        idx = np.arange(len(dataset)) if sub_index_list is None else sub_index_list
+        super().__init__(idx, num_replicas, rank)
+        self.sub_index_list = self.indices
 
 
 # --------------------------------------------------------------------------------------------- provider
@@ -206,13 +223,19 @@ class DataProvider(object):
     @staticmethod
     def random_sample_valid_set(train_size, valid_size):
         assert train_size > valid_size
-        g = torch.Generator()
-        g.manual_seed(DataProvider.VALID_SEED)
-        rand_indexes = torch.randperm(train_size, generator=g).tolist()
-        return rand_indexes[valid_size:], rand_indexes[:valid_size]
+        perm = torch.randperm(train_size, generator=torch.Generator().manual_seed(DataProvider.VALID_SEED)).tolist()
+        return perm[valid_size:], perm[:valid_size]
 
 
 class Div2K_SetXXDataProvider(DataProvider):
+    """DIV2K training crops + SetXX full-size validation images (interface of the reference's provider,
+    div2k_setxx.py:17-225: `train` / `valid` / `test` loaders, `data_shape`, `assign_active_img_size`,
+    `build_sub_train_loader`).
+
+    Sharding under data parallelism (num_replicas given): the TRAINING indices are split over the ranks by
+    RankShardSampler; the validation / test images are NOT split -- every rank evaluates the whole (14-image) set in
+    file order, so the logged PSNR, `best_acc` and `model_best` are the same on every rank count.  (The reference
+    wraps the test set in a shuffling, padding DistributedSampler with drop_last and never reduces the metric.)"""
     DEFAULT_PATH = "/SSD/div2k_setxx"
 
     def __init__(self, save_path=None, train_batch_size=256, test_batch_size=512, valid_size=None, n_worker=32,
@@ -221,62 +244,42 @@ class Div2K_SetXXDataProvider(DataProvider):
         if Image is None:
             raise ImportError("Div2K_SetXXDataProvider needs PIL")
         self._save_path = save_path
-        self.image_size = image_size
-        self.distort_color = distort_color
-        self.resize_scale = resize_scale
-        self._valid_transform_dict = {}
-        if not isinstance(self.image_size, int):
-            # the reference switches to MyDataLoader + MyRandomResizedCrop for multi-size training, but its SR
-            # transform list has that crop commented out (:167-176): only the largest size is ever active
-            assert isinstance(self.image_size, list)
-            self.image_size.sort()
-            for img_size in self.image_size:
-                self._valid_transform_dict[img_size] = self.build_valid_transform(img_size)
-            self.active_img_size = max(self.image_size)
-            valid_transforms = self._valid_transform_dict[self.active_img_size]
-        else:
-            self.active_img_size = self.image_size
-            valid_transforms = self.build_valid_transform()
-        loader = torch.utils.data.DataLoader
+        self.distort_color, self.resize_scale = distort_color, resize_scale
+        self._workers = n_worker
+        # a list of sizes selects multi-size training in the classification providers; the SR transform list has the
+        # resizing crop commented out (reference :167-176), so only the largest size is ever active
+        sizes = sorted(image_size) if isinstance(image_size, (list, tuple)) else [image_size]
+        self.image_size = image_size if isinstance(image_size, int) else sizes
+        self.active_img_size = sizes[-1]
+        self._valid_transform_dict = {sz: self.build_valid_transform(sz) for sz in sizes}
+        eval_tf = self._valid_transform_dict[self.active_img_size]
 
-        train_transforms = self.build_train_transform()
-        train_dataset = self.train_dataset(train_transforms)
+        train_set = self.train_dataset(self.build_train_transform())
+        sharded = num_replicas is not None and num_replicas > 1
+        n_train = len(train_set.samples)
+        train_idx, valid_idx = list(range(n_train)), None
         if valid_size is not None:
-            if not isinstance(valid_size, int):
-                assert isinstance(valid_size, float) and 0 < valid_size < 1
-                valid_size = int(len(train_dataset.samples) * valid_size)
-            valid_dataset = self.train_dataset(valid_transforms)
-            train_indexes, valid_indexes = self.random_sample_valid_set(len(train_dataset.samples), valid_size)
-            if num_replicas is not None:
-                train_sampler = MyDistributedSampler(train_dataset, num_replicas, rank, np.array(train_indexes))
-                valid_sampler = MyDistributedSampler(valid_dataset, num_replicas, rank, np.array(valid_indexes))
-            else:
-                train_sampler = torch.utils.data.sampler.SubsetRandomSampler(train_indexes)
-                valid_sampler = torch.utils.data.sampler.SubsetRandomSampler(valid_indexes)
-            self.train = loader(train_dataset, batch_size=train_batch_size, sampler=train_sampler,
-                                num_workers=n_worker, pin_memory=True, drop_last=True)
-            self.valid = loader(valid_dataset, batch_size=test_batch_size, sampler=valid_sampler,
-                                num_workers=n_worker, pin_memory=True, drop_last=True)
+            if isinstance(valid_size, float):
+                assert 0 < valid_size < 1
+                valid_size = int(n_train * valid_size)
+            train_idx, valid_idx = self.random_sample_valid_set(n_train, valid_size)
+        if sharded:
+            train_sampler = RankShardSampler(train_idx, num_replicas, rank)
+        elif valid_idx is not None:
+            train_sampler = torch.utils.data.SubsetRandomSampler(train_idx)
         else:
-            if num_replicas is not None:
-                train_sampler = DistributedSampler(train_dataset, num_replicas, rank)
-                self.train = loader(train_dataset, batch_size=train_batch_size, sampler=train_sampler,
-                                    num_workers=n_worker, pin_memory=True, drop_last=True)
-            else:
-                self.train = loader(train_dataset, batch_size=train_batch_size, shuffle=True, num_workers=n_worker,
-                                    pin_memory=True, drop_last=True)
-            self.valid = None
-
-        test_dataset = self.test_dataset(valid_transforms)
-        if num_replicas is not None:
-            test_sampler = DistributedSampler(test_dataset, num_replicas, rank)
-            self.test = loader(test_dataset, batch_size=test_batch_size, sampler=test_sampler, num_workers=n_worker,
-                               pin_memory=True, drop_last=True)
-        else:
-            self.test = loader(test_dataset, batch_size=test_batch_size, shuffle=True, num_workers=n_worker,
-                               pin_memory=True, drop_last=True)
-        if self.valid is None:
+            train_sampler = torch.utils.data.RandomSampler(train_set)
+        self.train = self._loader(train_set, train_batch_size, train_sampler, drop_last=True)
+        self.test = self._loader(self.test_dataset(eval_tf), test_batch_size, None, drop_last=False)
+        if valid_idx is None:
             self.valid = self.test
+        else:   # held-out training images, full set on every rank, fixed order
+            held_out = torch.utils.data.Subset(self.train_dataset(eval_tf), sorted(valid_idx))
+            self.valid = self._loader(held_out, test_batch_size, None, drop_last=False)
+
+    def _loader(self, dataset, batch_size, sampler, drop_last):
+        return torch.utils.data.DataLoader(dataset, batch_size=batch_size, sampler=sampler, shuffle=False,
+                                           num_workers=self._workers, pin_memory=True, drop_last=drop_last)
 
     @staticmethod
     def name():
@@ -292,19 +295,11 @@ class Div2K_SetXXDataProvider(DataProvider):
 
     @property
     def save_path(self):
-        if self._save_path is None:
-            self._save_path = self.DEFAULT_PATH
-        return self._save_path
+        return self._save_path or self.DEFAULT_PATH
 
     @property
     def data_url(self):
         raise ValueError("unable to download %s" % self.name())
-
-    def train_dataset(self, _transforms):
-        return Div2K_SetXXDataset(self.train_path, _transforms)
-
-    def test_dataset(self, _transforms):
-        return Div2K_SetXXDataset(self.valid_path, _transforms)
 
     @property
     def train_path(self):
@@ -314,43 +309,49 @@ class Div2K_SetXXDataProvider(DataProvider):
     def valid_path(self):
         return os.path.join(self.save_path, "val")
 
+    def train_dataset(self, _transforms):
+        return Div2K_SetXXDataset(self.train_path, _transforms)
+
+    def test_dataset(self, _transforms):
+        return Div2K_SetXXDataset(self.valid_path, _transforms)
+
     def build_train_transform(self, image_size=None, print_log=True):
-        if image_size is None:
-            image_size = self.image_size if isinstance(self.image_size, int) else max(self.image_size)
-        if self.distort_color in ("torch", "tf"):
-            raise NotImplementedError("ColorJitter needs torchvision (the SR scripts run with distort_color=None)")
-        return Compose([RandomCrop(image_size), RandomHorizontalFlip(), RandomRotation(degrees=(-90, 90))])
+        """RandomCrop -> RandomHorizontalFlip -> RandomRotation((-90, 90)) (reference :145-180; its resizing crop and
+        colour jitter are commented out / unused by the SR scripts, which pass distort_color=None)"""
+        if self.distort_color not in (None, "None"):
+            raise NotImplementedError("distort_color=%r: colour jitter needs torchvision, which this image lacks; the "
+                                      "SR entry scripts train with distort_color=None" % (self.distort_color,))
+        side = image_size if image_size is not None else self.active_img_size
+        return Compose([RandomCrop(side), RandomHorizontalFlip(), RandomRotation(degrees=(-90, 90))])
 
     def build_valid_transform(self, image_size=None):
         return Compose([ModCrop(mod=4)])
 
+    def _eval_datasets(self):
+        for loader in {id(self.valid): self.valid, id(self.test): self.test}.values():
+            ds = loader.dataset
+            yield ds.dataset if isinstance(ds, torch.utils.data.Subset) else ds
+
     def assign_active_img_size(self, new_img_size):
         self.active_img_size = new_img_size
-        if self.active_img_size not in self._valid_transform_dict:
-            self._valid_transform_dict[self.active_img_size] = self.build_valid_transform()
-        self.valid.dataset.transform = self._valid_transform_dict[self.active_img_size]
-        self.test.dataset.transform = self._valid_transform_dict[self.active_img_size]
+        tf = self._valid_transform_dict.setdefault(new_img_size, self.build_valid_transform(new_img_size))
+        for ds in self._eval_datasets():
+            ds.transform = tf
 
     def build_sub_train_loader(self, n_images, batch_size, num_worker=None, num_replicas=None, rank=None):
-        """loader of `n_images` fixed training images for BN re-calibration.  The reference caches a list of
-        `(images, labels)` tuples (:222-224), which its dict-yielding dataset cannot produce; the batches are kept
-        as the dicts the dataset yields (what set_running_statistics reads)."""
-        key = "sub_train_%d" % self.active_img_size
-        if self.__dict__.get(key, None) is None:
-            if num_worker is None:
-                num_worker = self.train.num_workers
-            n_samples = len(self.train.dataset.samples)
-            g = torch.Generator()
-            g.manual_seed(DataProvider.SUB_SEED)
-            rand_indexes = torch.randperm(n_samples, generator=g).tolist()
-            new_train_dataset = self.train_dataset(
-                self.build_train_transform(image_size=self.active_img_size, print_log=False))
-            chosen_indexes = rand_indexes[:n_images]
-            if num_replicas is not None:
-                sub_sampler = MyDistributedSampler(new_train_dataset, num_replicas, rank, np.array(chosen_indexes))
+        """`n_images` fixed training images (seed SUB_SEED) as a cached list of batches, for BN re-calibration
+        (reference :199-225).  The batches stay the dicts the dataset yields -- what set_running_statistics reads."""
+        cache = self.__dict__.setdefault("_sub_train_cache", {})
+        key = (self.active_img_size, n_images, batch_size)
+        if key not in cache:
+            ds = self.train_dataset(self.build_train_transform(image_size=self.active_img_size, print_log=False))
+            perm = torch.randperm(len(ds.samples), generator=torch.Generator().manual_seed(DataProvider.SUB_SEED))
+            chosen = perm[:n_images].tolist()
+            if num_replicas is not None and num_replicas > 1:
+                sampler = RankShardSampler(chosen, num_replicas, rank)
             else:
-                sub_sampler = torch.utils.data.sampler.SubsetRandomSampler(chosen_indexes)
-            sub_data_loader = torch.utils.data.DataLoader(new_train_dataset, batch_size=batch_size, sampler=sub_sampler,
-                                                          num_workers=num_worker, pin_memory=True)
-            self.__dict__[key] = [batch for batch in sub_data_loader]
-        return self.__dict__[key]
+                sampler = torch.utils.data.SubsetRandomSampler(chosen)
+            workers = self._workers if num_worker is None else num_worker
+            cache[key] = list(torch.utils.data.DataLoader(ds, batch_size=batch_size, sampler=sampler,
+                                                          num_workers=workers, pin_memory=True))
+        return cache[key]

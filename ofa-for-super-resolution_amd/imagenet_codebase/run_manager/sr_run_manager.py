@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from ... import distributed as dd
-from ...utils import AverageMeter, psnr_y
+from ...utils import AverageMeter, bucket_by_size, psnr_y, psnr_y_per_image
 from ..utils import get_net_info
 
 
@@ -293,6 +293,35 @@ class SRRunManager(object):
                 psnrs.update(psnr_y(output, images), images.size(0))
         return losses.avg, psnrs.avg
 
+    def validate_batched(self, net=None, data_loader=None, is_test=True, input_key="2x_down_image", max_batch=None):
+        """`validate` with the loader's batch-1 items of EQUAL size run as one batch (BASELINE config 5: Set14 at
+        full resolution, reference eval_ofa_net_sr.py:187-220,247-251 / sr_run_manager.py:323-393).  Loss and PSNR are
+        taken per image, so the result equals `validate` on the batch-1 loader (tests/test_hip_configs.py).
+        Returns (mean loss, mean PSNR, number of forward calls)."""
+        if net is None:
+            net = self.net
+        if data_loader is None:
+            data_loader = self.run_config.test_loader if is_test else self.run_config.valid_loader
+        net.eval()
+        items = []
+        for mini_batch in data_loader:
+            for i in range(mini_batch["image"].shape[0]):
+                items.append({k: v[i:i + 1] for k, v in mini_batch.items() if torch.is_tensor(v)})
+        losses, psnrs, calls = AverageMeter(), AverageMeter(), 0
+        with torch.no_grad():
+            for group in bucket_by_size(items, key=lambda it: it[input_key], max_batch=max_batch):
+                images = torch.cat([it["image"] for it in group]).to(self.device)
+                lr = torch.cat([it[input_key] for it in group]).to(self.device)
+                with self.autocast():
+                    output = net(lr).float()
+                calls += 1
+                per_img = ((output - images) ** 2).mean(dim=(1, 2, 3))
+                for v in per_img.tolist():
+                    losses.update(v, 1)
+                for v in psnr_y_per_image(output, images):
+                    psnrs.update(v, 1)
+        return losses.avg, psnrs.avg, calls
+
     def train_one_epoch(self, args, epoch, warmup_epochs=0, warmup_lr=0, input_key="2x_down_image"):
         """fixed-architecture ("teacher") epoch: BatchNorm layers run in eval mode (frozen statistics,
         reference :417-420), MSE loss, one optimizer step per batch.  Returns (mean loss, mean PSNR)."""
@@ -301,6 +330,9 @@ class SRRunManager(object):
             if isinstance(m, nn.BatchNorm2d):
                 m.eval()
         loader = self.run_config.train_loader
+        sampler = getattr(loader, "sampler", None)
+        if hasattr(sampler, "set_epoch"):      # a rank-sharding sampler replays the same permutation otherwise
+            sampler.set_epoch(epoch)
         nBatch = len(loader)
         losses, psnrs, data_time = AverageMeter(), AverageMeter(), AverageMeter()
         end = time.time()

@@ -192,6 +192,32 @@ def psnr_y(output, target):
     return psnr(rgb2y(tensor2img_np(output)), rgb2y(tensor2img_np(target)))
 
 
+def psnr_y_per_image(output, target):
+    """[psnr_y of every image of a batch on its own] -- what a batch-1 loader reports image by image.  The reference's
+    batch PSNR is taken over a make_grid mosaic, so a size-bucketed batch (eval_ofa_net_sr.py) must be
+    scored per image to reproduce the batch-1 numbers."""
+    return [psnr_y(output[i:i + 1], target[i:i + 1]) for i in range(output.shape[0])]
+
+
+def bucket_by_size(items, key=None, max_batch=None):
+    """group tensors (or records: `key(item)` -> the [1,C,H,W] tensor) of EQUAL spatial size, keeping first-seen
+    order: the size-bucketing BASELINE config 5 needs -- the reference evaluates Set14 at batch 1 because the images
+    differ in size (div2k_setxx.py:182-190); zero-padding to a common size would change the
+    pixels near the border (BN output of a padded zero is not zero), equal-size batching changes nothing.
+    Returns a list of lists."""
+    key = key or (lambda t: t)
+    order, groups = [], {}
+    for it in items:
+        shp = tuple(key(it).shape[-2:])
+        if shp not in groups:
+            groups[shp] = [[]]
+            order.append(shp)
+        if max_batch and len(groups[shp][-1]) >= max_batch:
+            groups[shp].append([])
+        groups[shp][-1].append(it)
+    return [chunk for shp in order for chunk in groups[shp]]
+
+
 class AverageMeter(object):
     """reference ofa/utils.py:53-75"""
 

@@ -109,11 +109,67 @@ def test_run_config_picks_real_provider_when_dataset_exists(dp, tmp_path, monkey
     cfg = rm.Div2K_SetXXRunConfig(train_batch_size=2, test_batch_size=1, n_worker=0, image_size=32)
     assert (cfg.distort_color, cfg.image_size) == (None, 32)   # the reference's defaults (run_manager/__init__.py:134)
     monkeypatch.setenv("OFASR_DIV2K_ROOT", str(tmp_path / "missing"))
-    cfg0 = rm.Div2K_SetXXRunConfig(train_batch_size=2, test_batch_size=1, n_worker=0, image_size=32)
-    assert cfg0.data_provider.name() == "synthetic_sr"
+    monkeypatch.delenv("OFASR_ALLOW_SYNTHETIC_DATA", raising=False)
+    with pytest.raises(FileNotFoundError):      # a mistyped dataset path must not train on noise silently
+        rm.Div2K_SetXXRunConfig(train_batch_size=2, test_batch_size=1, n_worker=0, image_size=32).data_provider
+    cfg0 = rm.Div2K_SetXXRunConfig(train_batch_size=2, test_batch_size=1, n_worker=0, image_size=32,
+                                   allow_synthetic=True)
+    assert cfg0.data_provider.name() == "synthetic_sr" and "synthetic" in cfg0.dataset and "synthetic" in cfg0.config["dataset"]
     _tree(str(tmp_path))
     monkeypatch.setenv("OFASR_DIV2K_ROOT", str(tmp_path))
     cfg1 = rm.Div2K_SetXXRunConfig(train_batch_size=2, test_batch_size=1, n_worker=0, image_size=32)
     prov = cfg1.data_provider
     assert isinstance(prov, dp.Div2K_SetXXDataProvider) and prov is cfg1.data_provider
     assert tuple(next(iter(cfg1.train_loader))["image"].shape) == (2, 3, 32, 32)
+
+
+def test_training_script_settings_build_the_real_provider(dp, tmp_path, monkeypatch):
+    """the run config exactly as train_ofa_net_sr_simple.py builds it (Div2K_SetXXRunConfig(**args.__dict__) with the
+    script's hard-coded settings, reference train_ofa_net_sr_simple.py:88-132) against a tiny on-disk PNG tree: the
+    provider constructs and yields a batch (distort_color must be None as in the reference, :115)."""
+    import argparse
+    import re
+    from conftest import ROOT
+    rm = amd("imagenet_codebase.run_manager")
+    src = open(os.path.join(ROOT, "train_ofa_net_sr_simple.py")).read()
+    m = re.search(r"args\.resize_scale, args\.distort_color = ([^\n#]+)", src)
+    resize_scale, distort_color = eval(m.group(1))
+    assert distort_color is None
+    args = argparse.Namespace(
+        task="kernel", phase=1, path=str(tmp_path / "exp"), n_epochs=1, base_lr=1e-3, dynamic_batch_size=1,
+        manual_seed=0, lr_schedule_type="cosine", base_batch_size=16, valid_size=None, opt_type="adam", momentum=0.9,
+        no_nesterov=False, weight_decay=3e-5, label_smoothing=0.0, no_decay_keys="bn#bias", fp16_allreduce=False,
+        model_init="he_fout", validation_frequency=1, print_frequency=10, n_worker=0, resize_scale=resize_scale,
+        distort_color=distort_color, image_size=32, continuous_size=True, not_sync_distributed_image_size=False,
+        bn_momentum=0.1, bn_eps=1e-5, dropout=0.1, width_mult_list="1.0", dy_conv_scaling_mode=1,
+        independent_distributed_sampling=False, kd_ratio=0, kd_type="ce", teacher_model=None, warmup_epochs=0,
+        warmup_lr=-1, init_lr=1e-3, train_batch_size=2, test_batch_size=1)
+    _tree(str(tmp_path / "data"))
+    monkeypatch.setenv("OFASR_DIV2K_ROOT", str(tmp_path / "data"))
+    cfg = rm.Div2K_SetXXRunConfig(**args.__dict__)
+    prov = cfg.data_provider
+    assert isinstance(prov, dp.Div2K_SetXXDataProvider)
+    b = next(iter(cfg.train_loader))
+    assert tuple(b["image"].shape) == (2, 3, 32, 32) and tuple(b["4x_down_image"].shape) == (2, 3, 8, 8)
+
+
+def test_eval_loaders_are_whole_and_ordered_under_sharding(dp, tmp_path):
+    """data parallelism: training indices are split over the ranks and re-shuffled per epoch (set_epoch); validation /
+    test images are NOT split -- every rank sees every image once, in file order (no shuffle, no padding duplicates,
+    no drop_last), so the logged PSNR does not depend on the rank count."""
+    _tree(str(tmp_path), n_train=7, n_val=3)
+    provs = [dp.Div2K_SetXXDataProvider(save_path=str(tmp_path), train_batch_size=1, test_batch_size=1, n_worker=0,
+                                        image_size=32, num_replicas=2, rank=r) for r in range(2)]
+    shapes = [[tuple(b["image"].shape) for b in p.test] for p in provs]
+    assert shapes[0] == shapes[1] and len(shapes[0]) == 3
+    assert sorted(s[2:] for s in shapes[0]) == [(36, 48), (36, 52), (36, 52)]     # 37x50, 38x52, 39x54 after ModCrop(4)
+    assert shapes[0] == [tuple(b["image"].shape) for b in provs[0].test]             # same (listing) order every pass
+    per_epoch = []
+    for epoch in (0, 1):
+        idx = []
+        for p in provs:
+            p.train.sampler.set_epoch(epoch)
+            idx.append(list(iter(p.train.sampler)))
+        assert len(idx[0]) == len(idx[1]) == 4 and set(idx[0] + idx[1]) == set(range(7))
+        per_epoch.append(idx)
+    assert per_epoch[0] != per_epoch[1]

@@ -7,8 +7,8 @@ the same `args` attribute names, reference :21-132), one process per GPU:
     python -m torch.distributed.run --nproc-per-node 8 train_ofa_net_sr_simple.py --task depth --phase 1
 
 Differences from the reference script: hyper-parameters that it edits in source are flags here
-(--net s4|x4, --teacher-path, --path, --mix-prec); DIV2K is replaced by the synthetic provider when the
-dataset directory is absent; multi-GPU is RCCL data parallelism (one flat all-reduce per step)."""
+(--net s4|x4, --teacher-path, --path, --mix-prec); with --synthetic the synthetic provider stands in for a missing
+DIV2K directory (otherwise a missing dataset is an error); multi-GPU is RCCL data parallelism (one flat all-reduce per step)."""
 import argparse
 import importlib
 import os
@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--n-epochs", type=int, default=None)
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--n-train-batches", type=int, default=8)
+    ap.add_argument("--synthetic", action="store_true", help="train on synthetic images when DIV2K is absent")
     args = ap.parse_args()
 
     import numpy as np
@@ -78,7 +79,7 @@ def main():
     args.validation_frequency = 1
     args.print_frequency = 10
     args.n_worker = 8
-    args.resize_scale, args.distort_color = 0.35, "tf"
+    args.resize_scale, args.distort_color = 0.35, None      # reference :115 (colour jitter off)
     args.continuous_size, args.not_sync_distributed_image_size = True, False
     args.bn_momentum, args.bn_eps = 0.1, 1e-5
     args.dropout = 0.1
@@ -100,6 +101,7 @@ def main():
     nets = importlib.import_module(PKG + ".elastic_nn.networks")
     ps = importlib.import_module(PKG + ".elastic_nn.training.progressive_shrinking")
 
+    args.allow_synthetic = True if args.synthetic else None
     run_config = rm.Div2K_SetXXRunConfig(**args.__dict__)
     dop.DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = args.dy_conv_scaling_mode
     to_list = lambda s, f: [f(x) for x in s.split(",")]
@@ -114,9 +116,6 @@ def main():
     run_manager = rm.SRRunManager(args.path, net, run_config, mix_prec=args.mix_prec,
                                   num_gpus=int(os.environ.get("WORLD_SIZE", "1")), args=args)
     run_manager.save_config()
-    if args.net == "s4" and max(args.pixelshuffle_depth_list) == 2:
-        orig = run_manager.validate       # a 4x net validates on the 4x input (reference quirk Q4)
-        run_manager.validate = lambda **kw: orig(input_key="4x_down_image", **kw)
 
     validate_func_dict = {"image_size_list": None, "width_mult_list": None,
                           "ks_list": sorted({min(args.ks_list), max(args.ks_list)}),

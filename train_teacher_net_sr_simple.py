@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--expand", type=int, default=3)
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--pixelshuffle-depth", type=int, default=1)
+    ap.add_argument("--synthetic", action="store_true", help="train on synthetic images when DIV2K is absent")
     a = ap.parse_args()
 
     import numpy as np
@@ -41,7 +42,8 @@ def main():
     args = argparse.Namespace(teacher_model=None, kd_ratio=0, kd_type="ce")
     cfg = rm.Div2K_SetXXRunConfig(n_epochs=a.n_epochs, init_lr=1e-3, opt_type="adam", weight_decay=3e-5,
                                   no_decay_keys="bn#bias", label_smoothing=0.0, train_batch_size=a.batch,
-                                  test_batch_size=1, image_size=a.image_size, n_worker=8)
+                                  test_batch_size=1, image_size=a.image_size, n_worker=8,
+                                  allow_synthetic=True if a.synthetic else None)
     net = nets.OFAMobileNetS4(ks_list=[a.ks], expand_ratio_list=[a.expand], depth_list=[a.depth],
                               pixelshuffle_depth_list=[a.pixelshuffle_depth])
     mgr = rm.SRRunManager(a.path, net, cfg, mix_prec=a.mix_prec, num_gpus=int(os.environ.get("WORLD_SIZE", "1")),
