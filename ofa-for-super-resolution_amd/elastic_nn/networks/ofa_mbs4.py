@@ -231,6 +231,11 @@ class OFAMobileNetS4(MobileNetS4):
         return {"wid": None, "ks": ks_setting, "e": expand_setting, "d": depth_setting, "pixel_d": pd_setting}
 
     def re_organize_middle_weights(self, expand_ratio_stage=0):
+        """sort every MB block's middle channels by importance (reference ofa_mbs4.py:462-464).  As committed the
+        reference walks `self.blocks[2:-2]` -- a slice inherited from the classification supernet, whose first block
+        is a fixed stem -- so the FIRST TWO MB blocks of the SR net are never re-organised (pinned by
+        tests/golden/reorganize.npz); COMPAT_REFERENCE_INDEXING=False re-organises all of them."""
         n_mb = len(self.blocks) - len(self.block_group_info[_N_MB_STAGES])
-        for block in self.blocks[:n_mb]:
+        first = 2 if self.COMPAT_REFERENCE_INDEXING else 0
+        for block in self.blocks[first:n_mb]:
             block.mobile_inverted_conv.re_organize_middle_weights(expand_ratio_stage)

@@ -141,12 +141,15 @@ def s4_forward(sd, x, arch, training, transform=True, momentum=0.1, eps=1e-5, co
     h = _conv_layer(sd, "dec_final_conv_blocks.0.", h, training, momentum, eps) + skip
     h = _conv_layer(sd, "dec_final_conv_blocks.1.", h, training, momentum, eps)
     d_shuffle = arch.runtime_depth[0] if compat else arch.runtime_depth[4]
-    for idx in GROUPS[4][:d_shuffle]:
+    # the net holds max(pixelshuffle_depth_list) conv+PixelShuffle blocks (ofa_mbs4.py:111-120): a 2x-only supernet
+    # (pixelshuffle_depth_list=[1], BASELINE configs 1 and 2) has no blocks.17
+    shuffle_group = [i for i in GROUPS[4] if ("blocks.%d.conv.weight" % i) in sd]
+    for idx in shuffle_group[:d_shuffle]:
         h = _conv_layer(sd, "blocks.%d." % idx, h, training, momentum, eps, shuffle=True)
     return _conv_layer(sd, "dec_final_output_conv_block.", h, training, momentum, eps)
 
 
-def state_dict_shapes(ks_max=7, e_max=6, transform=True):
+def state_dict_shapes(ks_max=7, e_max=6, transform=True, n_shuffle=2):
     """the reference's 356-entry state dict layout for the full S4 supernet."""
     shapes = {}
 
@@ -169,7 +172,7 @@ def state_dict_shapes(ks_max=7, e_max=6, transform=True):
         bn(p + "depth_conv.bn.bn.", mid)
         shapes[p + "point_linear.conv.conv.weight"] = (64, mid, 1, 1)
         bn(p + "point_linear.bn.bn.", 64)
-    for i in (16, 17):
+    for i in (16, 17)[:n_shuffle]:
         shapes["blocks.%d.conv.weight" % i] = (256, 64, 5, 5)
         bn("blocks.%d.bn." % i, 256)
     shapes["dec_first_conv_block.conv.weight"] = (64, 3, 5, 5)

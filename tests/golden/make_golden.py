@@ -38,7 +38,23 @@ def _stub_torchvision():
         # used by the goldens.
         if tensor.dim() == 4 and tensor.size(0) == 1:
             return tensor.squeeze(0)
-        raise NotImplementedError("golden generation uses batch-1 PSNR only")
+        # torchvision.utils.make_grid restated for batches > 1 (torchvision itself is absent; this layout is
+        # torchvision's documented one, NOT the reference's code -- "parity unpinned" for the mosaic, see gen_teacher):
+        # xmaps = min(nrow, N) columns, cells of (H + padding) x (W + padding), zero fill, image (y, x) at
+        # (y*(H+padding) + padding, x*(W+padding) + padding)
+        n, c, h, w = tensor.shape
+        xmaps = min(nrow, n)
+        ymaps = int(math.ceil(float(n) / xmaps))
+        ch, cw = h + padding, w + padding
+        grid = tensor.new_zeros((c, ch * ymaps + padding, cw * xmaps + padding))
+        k = 0
+        for yy in range(ymaps):
+            for xx in range(xmaps):
+                if k >= n:
+                    break
+                grid[:, yy * ch + padding:yy * ch + padding + h, xx * cw + padding:xx * cw + padding + w] = tensor[k]
+                k += 1
+        return grid
 
     tv = types.ModuleType("torchvision")
     tvu = types.ModuleType("torchvision.utils")
@@ -519,7 +535,108 @@ def gen_trainer():
     print("wrote trainer_meta.json")
 
 
+def gen_teacher():
+    """the fixed-architecture ("teacher") loop through the REFERENCE's own SRRunManager on CPU
+    (sr_run_manager.py:138-198 ctor, :413-514 train_one_epoch with frozen BN, :323-393 validate): S4(ks=[5], e=[3],
+    d=[2], pd=[1]) as train_teacher_net_sr_simple.py:186 builds it, Adam with the bn/bias no-decay groups, cosine LR,
+    three fixed batches [4,3,32,32] / [4,3,16,16], then validate() on two batch-1 images of different size.
+    Recorded: (loss, psnr) of the epoch and of the validation, every post-epoch parameter, the BN buffers (untouched:
+    frozen).  The training PSNR goes through make_grid (batch 4 mosaic) -- restated above from
+    torchvision's documented layout because torchvision is absent; the batch-1 validation PSNR does not."""
+    import argparse
+    import tempfile
+    from ofa.elastic_nn.networks import OFAMobileNetS4
+    from ofa.imagenet_codebase.run_manager.sr_run_manager import RunConfig, SRRunManager
+    DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = 1
+    net = OFAMobileNetS4(ks_list=[5], expand_ratio_list=[3], depth_list=[2], pixelshuffle_depth_list=[1])
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+
+    class Provider(object):
+        data_shape = (3, 32, 32)
+        image_size = 32
+
+        def __init__(self):
+            self.train = [{"image": T(det_uniform((4, 3, 32, 32), "teach/hr%d" % i, 0.0, 1.0)),
+                           "2x_down_image": T(det_uniform((4, 3, 16, 16), "teach/x2_%d" % i, 0.0, 1.0))} for i in range(3)]
+            self.test = [{"image": T(det_uniform((1, 3) + hw, "teach/vhr%d" % i, 0.0, 1.0)),
+                          "2x_down_image": T(det_uniform((1, 3, hw[0] // 2, hw[1] // 2), "teach/vx2_%d" % i, 0.0, 1.0))}
+                         for i, hw in enumerate([(32, 32), (24, 40)])]
+            self.valid = self.test
+
+    class Cfg(RunConfig):
+        _prov = Provider()
+
+        @property
+        def data_provider(self):
+            return self._prov
+
+    cfg = Cfg(n_epochs=2, init_lr=1e-4, lr_schedule_type="cosine", lr_schedule_param=None, dataset="x",
+              train_batch_size=4, test_batch_size=1, valid_size=None, opt_type="adam", opt_param=None,
+              weight_decay=3e-5, label_smoothing=0.0, no_decay_keys="bn#bias", mixup_alpha=None,
+              model_init="he_fout", validation_frequency=1, print_frequency=1)
+    # the args the script hands over (train_teacher_net_sr_simple.py:79-126, lists as :165-180 converts them)
+    args = argparse.Namespace(teacher_model=None, kd_ratio=0.0, kd_type=None, ks_list=[5], expand_list=[3],
+                              depth_list=[2], pixelshuffle_depth_list=[1])
+    with tempfile.TemporaryDirectory() as d:
+        mgr = SRRunManager(d, net, cfg, init=True, no_gpu=True, num_gpus=1, args=args)
+        sd = fill_state_dict(shapes, "teach")
+        net.load_state_dict({k: T(v) for k, v in sd.items()})
+        out = {}
+        v0 = mgr.validate(is_test=True, no_logs=True)
+        out["valid_before"] = np.array(v0, dtype=np.float64)
+        tr = mgr.train_one_epoch(args, 0)
+        out["train_epoch0"] = np.array(tr, dtype=np.float64)
+        v1 = mgr.validate(is_test=True, no_logs=True)
+        out["valid_after"] = np.array(v1, dtype=np.float64)
+    names = [n for n, _ in net.named_parameters()]
+    out["w_sum"] = np.array([float(p.detach().double().sum()) for _, p in net.named_parameters()])
+    out["w_l2"] = np.array([float(p.detach().double().pow(2).sum().sqrt()) for _, p in net.named_parameters()])
+    out["w_changed"] = np.array([not np.array_equal(sd[n], A(p)) for n, p in net.named_parameters()])
+    pd = dict(net.named_parameters())
+    for k in ["dec_first_conv_block.conv.weight", "blocks.0.mobile_inverted_conv.inverted_bottleneck.conv.conv.weight",
+              "blocks.0.mobile_inverted_conv.depth_conv.conv.conv.weight",
+              "blocks.7.mobile_inverted_conv.point_linear.conv.conv.weight",
+              "blocks.7.mobile_inverted_conv.depth_conv.bn.bn.weight", "dec_final_output_conv_block.conv.weight",
+              "dec_final_output_conv_block.bn.bias"]:
+        out["w_" + k] = A(pd[k])
+    out["buffers_untouched"] = np.array(all(np.array_equal(sd[k], A(v)) for k, v in net.named_buffers()))
+    out["lr_last"] = np.array(mgr.optimizer.param_groups[0]["lr"])
+    with open(os.path.join(HERE, "teacher_meta.json"), "w") as f:
+        json.dump({"param_names": names}, f, indent=1)
+    DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = None
+    save("teacher.npz", **out)
+
+
+def gen_reorganize():
+    """DynamicMBConvLayer.re_organize_middle_weights (dynamic_layers.py:156-199) and the net-level driver
+    (ofa_mbs4.py:462-464) as supporting_elastic_expand uses them (progressive_shrinking.py:331-396): stage 0 on the
+    det-filled weights, then stage 1 on the result.  Recorded: every tensor of the layer after each call, and the first
+    and last MB block of an S4 net after net.re_organize_middle_weights(0) then (1)."""
+    from ofa.elastic_nn.networks import OFAMobileNetS4
+    DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = 1
+    layer = DynamicMBConvLayer([16], [16], [3, 5, 7], [3, 4, 6], stride=1, act_func="relu6")
+    _load_sd(layer, "reorg")
+    out = {}
+    for stage in (0, 1, 2):
+        layer.re_organize_middle_weights(expand_ratio_stage=stage)
+        for k, v in layer.state_dict().items():
+            out["layer_s%d_%s" % (stage, k)] = A(v)
+    net = OFAMobileNetS4(ks_list=[3, 5, 7], expand_ratio_list=[3, 4, 6], depth_list=[2, 3, 4],
+                         pixelshuffle_depth_list=[1, 2])
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = fill_state_dict(shapes, "s4")
+    net.load_state_dict({k: T(v) for k, v in sd.items()})
+    for stage in (0, 1):
+        net.re_organize_middle_weights(expand_ratio_stage=stage)
+        for k, v in net.state_dict().items():
+            if k.startswith("blocks.0.") or k.startswith("blocks.15."):
+                out["net_s%d_%s" % (stage, k)] = A(v)
+    DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = None
+    save("reorganize.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pwconv", "dwconv", "bn", "pixelshuffle", "mbblock", "s4", "metric", "trainer", "calibration", "div2k"]
+    which = sys.argv[1:] or ["pwconv", "dwconv", "bn", "pixelshuffle", "mbblock", "s4", "metric", "trainer", "calibration",
+                             "div2k", "teacher", "reorganize"]
     for w in which:
         globals()["gen_" + w]()

@@ -1,0 +1,41 @@
+"""bench.py's training step (TrainWorkload: the objects the timed region runs) against the network-level CPU oracle
+(oracle/s4_port.py) on the same weights, inputs, sub-network seeds and Adam groups: the loss trajectory bench.py reports
+as `final_loss` is the reference algorithm's.  `-m gpu`.  Reference: progressive_shrinking.py:152-203 (hot loop),
+sr_run_manager.py:115-133,180-191 (Adam, weight-decay groups)."""
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("bf16", 2e-2)])
+def test_bench_train_step_losses_match_the_oracle_port(dtype, tol):
+    import bench
+    from oracle import s4_port
+    dev = torch.device("cuda", 0)
+    M = bench.mods()
+    wl = bench.TrainWorkload(M, "c3", dev, batch=2, lr_size=16, dtype=dtype)
+    sd = {k: v.detach().cpu().clone() for k, v in wl.net.state_dict().items()}
+    decay, no_decay = [], []
+    for k, v in sd.items():
+        if s4_port.is_param(k):
+            v.requires_grad_(True)
+            (no_decay if ("bn" in k or "bias" in k) else decay).append(v)
+    opt = torch.optim.Adam([{"params": decay, "weight_decay": 3e-5}, {"params": no_decay, "weight_decay": 0}], lr=1e-3)
+    arch = s4_port.Arch(ks_list=(3, 5, 7), expand_list=(6,), depth_list=(4,), pd_list=(2,))
+    hr, lr = wl.hr.cpu(), wl.lr.cpu()
+    ref, got = [], []
+    for i in range(3):
+        opt.zero_grad(set_to_none=True)
+        random.seed(bench.subnet_seed(i))
+        arch.sample_active_subnet()
+        loss = F.mse_loss(s4_port.s4_forward(sd, lr, arch, training=True), hr)
+        loss.backward()
+        opt.step()
+        ref.append(float(loss))
+        got.append(float(wl.step(i)))
+    for a, b in zip(got, ref):
+        assert abs(a - b) <= tol * abs(b), (dtype, got, ref)

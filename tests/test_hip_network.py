@@ -191,20 +191,60 @@ def test_s4_vs_oracle_random_subnet_and_bf16(mods, meta):
     tot_a = torch.cat([p.grad.detach().cpu().double().flatten() for _, p in net.named_parameters() if p.grad is not None])
     tot_b = torch.cat([sd[n].grad.double().flatten() for n, p in net.named_parameters() if p.grad is not None])
     assert float((tot_a - tot_b).norm() / tot_b.norm()) < 2e-2
-    # bf16 activations (fp32 master weights, fp32 accumulation): a sanity bound, not a parity claim
-    net.zero_grad()
-    _load(net, "s4")
-    net.to(DEV)
+
+
+def test_s4_bf16_whole_net_gradient_error_vs_oracle(mods):
+    """bf16 activations (fp32 master weights, fp32 accumulation) on the timed path's shapes: a he_fout-initialised S4
+    supernet (the state a training run starts from; the det-filled net above is chaotic in backward), N=4, LR 64x64,
+    sampled sub-network, train-mode BN -- output, loss and the WHOLE-NET relative gradient error
+    ||g_hip - g_oracle|| / ||g_oracle|| over all 2.16 M parameters against the fp32 network oracle, plus the same per
+    tensor for the tensors that carry 99 % of the gradient energy."""
+    from oracle import s4_port
+    torch.manual_seed(21)
+    net = mods["nets"].OFAMobileNetS4(ks_list=[3, 5, 7], expand_ratio_list=[3, 4, 6], depth_list=[2, 3, 4],
+                                      pixelshuffle_depth_list=[1, 2])
+    net.init_model("he_fout")
+    net.to(DEV).train()
+    random.seed(77)
+    sampled = net.sample_active_subnet()
+    arch = s4_port.Arch()
+    random.seed(77)
+    assert arch.sample_active_subnet() == sampled
+    g = torch.Generator().manual_seed(5)
+    scale = net.active_upscale()
+    hr = torch.rand((4, 3, 64 * scale, 64 * scale), generator=g)
+    lr = F.interpolate(hr, scale_factor=1.0 / scale, mode="bicubic", antialias=True).clamp_(0, 1)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    for k, v in sd.items():
+        if s4_port.is_param(k):
+            v.requires_grad_(True)
+    y_ref = s4_port.s4_forward(sd, lr, arch, training=True)
+    loss_ref = F.mse_loss(y_ref, hr)
+    loss_ref.backward()
     with torch.autocast("cuda", dtype=torch.bfloat16):
-        yb = net(G(lr))
+        yb = net(lr.to(DEV))
     assert yb.dtype == torch.bfloat16
-    err = float((yb.float().cpu() - y_ref.detach()).abs().max())
-    assert err < 0.05 * max(1.0, float(y_ref.detach().abs().max())), err
-    F.mse_loss(yb.float(), hr.to(DEV)).backward()
-    gb = dict(net.named_parameters())["dec_first_conv_block.conv.weight"].grad
-    gr = sd["dec_first_conv_block.conv.weight"].grad
-    cos = float(F.cosine_similarity(gb.flatten().cpu().float(), gr.flatten(), dim=0))
-    assert cos > 0.9, cos
+    loss = F.mse_loss(yb.float(), hr.to(DEV))
+    loss.backward()
+    rel_y = float((yb.float().cpu() - y_ref.detach()).norm() / y_ref.detach().norm())
+    pairs = [(n, p.grad.detach().double().cpu().flatten(), sd[n].grad.double().flatten())
+             for n, p in net.named_parameters() if p.grad is not None]
+    for n, p in net.named_parameters():
+        assert (p.grad is None) == (sd[n].grad is None), n
+    ga, gb = torch.cat([a for _, a, _ in pairs]), torch.cat([b for _, _, b in pairs])
+    whole = float((ga - gb).norm() / gb.norm())
+    energy = sorted(((float(b.norm() ** 2), n, float((a - b).norm() / (b.norm() + 1e-30))) for n, a, b in pairs), reverse=True)
+    tot, acc, worst = sum(e for e, _, _ in energy), 0.0, 0.0
+    for e, n, r in energy:
+        worst = max(worst, r)
+        acc += e
+        if acc >= 0.99 * tot:
+            break
+    print("bf16 S4: loss %.6f vs %.6f, output rel %.4g, whole-net gradient rel %.4g, worst dominant tensor %.4g"
+          % (float(loss), float(loss_ref), rel_y, whole, worst))
+    assert abs(float(loss) - float(loss_ref)) <= 2e-2 * float(loss_ref)
+    assert rel_y <= 2e-2
+    assert whole <= 0.12 and worst <= 0.25
 
 
 def test_get_active_subnet_matches_supernet(mods):
