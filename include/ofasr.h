@@ -232,6 +232,22 @@ int ofasr_mbconv_join(void* stream);
 void* ofasr_side_stream(void);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused MB block, eval-mode / frozen BatchNorm, forward only (csrc/mbfused.hip): with bn_training[] all 0 the three
+ * BNs are affine maps (running statistics) and fold into their convolutions, so the whole block
+ *     out = x + BN3(W2 . relu6(BN2(dw_k(relu6(BN1(W1 . x))))))         (residual = 0: without the x +)
+ * is ONE kernel that reads x once and writes out once; the mid tensor never leaves the CU.  The regime of
+ * SRRunManager.validate / eval_ofa_net_sr.py (reference sr_run_manager.py:323-393, net.eval()) and of the frozen-BN
+ * teacher's forward (:417-420).  Supported: f16 / bf16 activations, Cin = Cout = 64, mid % 32 == 0, K in {3,5,7}, any
+ * N, H, W (ofasr_mbconv_infer_supported; otherwise OFASR_ERR_UNSUPPORTED and the caller uses ofasr_mbconv_fwd).
+ * The descriptor is ofasr_mbconv_fwd's (running statistics are only read).  workspace: the per-call folded 16-bit
+ * operand images, ofasr_mbconv_infer_workspace(d) bytes.  x and out must not overlap.
+ * ------------------------------------------------------------------------------------------- */
+int ofasr_mbconv_infer_supported(const ofasr_mbconv_desc* d);
+size_t ofasr_mbconv_infer_workspace(const ofasr_mbconv_desc* d);
+int ofasr_mbconv_infer(const ofasr_mbconv_desc* d, const void* x, void* out, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Dense KxK convolution (K in {3,5}, stride 1, zero padding K/2, no bias) of the static ConvLayers as an
  * implicit GEMM on the matrix cores  -- replaces nn.Conv2d in ConvLayer (reference ofa/layers.py:131-151) for
  * 16-bit activations: forward, input gradient and weight gradient.
@@ -249,6 +265,17 @@ int ofasr_conv2d_dgrad(const void* dy, const float* w, void* dx, int64_t N, int6
 size_t ofasr_conv2d_wgrad_workspace(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K);
 int ofasr_conv2d_wgrad(const void* dy, const void* x, float* dw, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
                        int64_t W, int K, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * PIL-exact 8-bit bicubic resize  -- replaces the host-side img.resize(size, Image.BICUBIC) that makes the
+ * reference's LR images (Scale(1/2), Scale(1/4): ofa/imagenet_codebase/data_providers/div2k_setxx.py:354-380, called
+ * per sample at :288-298).  src / dst are uint8 PLANES ([planes, in_h, in_w] -> [planes, out_h, out_w], planes = N*3
+ * for CHW images); the result equals Pillow's fixed-point resampling bit for bit (horizontal pass, then vertical;
+ * 22-bit coefficients computed on the device in double).  Down-scale factors up to 8; workspace from the query.
+ * ------------------------------------------------------------------------------------------- */
+size_t ofasr_bicubic_resize_u8_workspace(int64_t planes, int64_t in_h, int64_t in_w, int64_t out_h, int64_t out_w);
+int ofasr_bicubic_resize_u8(const void* src, void* dst, int64_t planes, int64_t in_h, int64_t in_w, int64_t out_h,
+                            int64_t out_w, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Diagnostics (tests and bench.py; nothing on the product path calls these).

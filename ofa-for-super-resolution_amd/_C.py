@@ -75,6 +75,11 @@ SIGNATURES = {
     "ofasr_mbconv_defer_join": (_c_int, [_c_int]),
     "ofasr_mbconv_join": (_c_int, [_c_vp]),
     "ofasr_side_stream": (_c_vp, []),
+    "ofasr_bicubic_resize_u8_workspace": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
+    "ofasr_bicubic_resize_u8": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp, _c_sz, _c_vp]),
+    "ofasr_mbconv_infer_supported": (_c_int, [_c_vp]),
+    "ofasr_mbconv_infer_workspace": (_c_sz, [_c_vp]),
+    "ofasr_mbconv_infer": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "ofasr_debug_launch_count": (ctypes.c_longlong, [ctypes.c_char_p]),
     "ofasr_debug_reset_launch_counts": (None, []),
     "ofasr_debug_launch_table": (ctypes.c_char_p, []),

@@ -1,0 +1,484 @@
+// mbfused.hip -- the WHOLE MB block as ONE kernel for eval-mode / frozen BatchNorm (ofasr_mbconv_infer):
+//     out = x + BN3(W2 . relu6(BN2(dw_k(relu6(BN1(W1 . x))))))
+// DynamicMBConvLayer.forward + the identity shortcut (reference ofa/elastic_nn/modules/dynamic_layers.py:70-84,
+// ofa/imagenet_codebase/networks/proxyless_nets.py:44-51) in the BN regime the reference validates in
+// (sr_run_manager.py:323-393 net.eval(), eval_ofa_net_sr.py:187-220) -- and freezes its teacher BN in (:417-420).
+//
+// With running statistics every BN is an affine map, so it folds into its conv: W1f = s1.W1 (rows), b1;
+// taps f.s2, b2; W2f = s3.W2, b3 (mb_fold_kernel; 16-bit operands, fp32 biases).  The block then reads x ONCE and writes
+// out ONCE: 2 x 8.4 MB per call at N=16, 64x64 (25 MB with the shortcut read) instead of the 243 MB the un-fused eval path
+// moves through y1 / y2 / y3 -- the mid tensor (384 channels) never leaves the CU.  This is the variant in which the
+// 1x1 path is matrix-bound.
+//
+// One workgroup (8 waves) = one 16x16 output tile of one image, all channels:
+//   prologue  the x window (16+2P rows x 24 columns, image columns w0-4 .. w0+19: 8-byte aligned quads) of all 64
+//             channels -> LDS; every wave pulls the MFMA fragments of its <= 3 blocks of 32 window pixels into
+//             registers (transposing reads); the LDS image is then dead and its space reused
+//   per chunk of 32 mid channels (mid/32 chunks), software-pipelined over two barriers:
+//     E  expand on the matrix cores: a1[32 px x 32 ch] = X^T[32 px x 64] . W1f^T[64 x 32] per pixel block, + b1, ReLU6,
+//        positions outside the image forced to 0 (the depthwise conv pads the ACTIVATED tensor with zeros), 16-bit,
+//        written as channel planes (4 adjacent pixels per lane: the accumulator rows) -> A1[buf]
+//     D  depthwise k x k on the vector pipe from the planes: a lane owns 4 adjacent outputs of one row; two taps per
+//        v_dot2c_f32_{bf16,f16} (fp32 accumulation of exact 16-bit products): the pair tables E = (f0 f1)(f2 f3).. and
+//        O = (0 f0)(f1 f2).. make every pair sit on an aligned dword of the plane whatever the output's parity, taps are
+//        wave-uniform (scalar loads), + b2, ReLU6, 16-bit -> A2
+//     P  project on the matrix cores: out[32 px x 64] += a2^T[32 px x 32 ch] . W2f^T[32 x 64]  (accumulators resident)
+//     waves 4-7 run D before E so that the two waves of a SIMD are on different pipes (matrix || vector)
+//   epilogue  + b3 (+ x), staged through LDS so that the tile leaves as 16-byte row pieces.
+//
+// Bounds (N=16, 64x64, mid 384, bf16): HBM 25 MB -> 4.6 us; matrix work 2*(1.89*64*384 + 384*64)*65536*... = 9.3 GFLOP
+// at k=7 (the window re-computes the expand 1.89x; 7.3 GFLOP at k=3) -> 3.7 us at the 2.5 PF peak; depthwise k=7
+// 28 v_dot2c per output = 43 k wave-instructions per CU.  DESIGN.md section 3 has the measured numbers.
+#include "ofasr_common.h"
+
+namespace ofasr {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int MF_THREADS = 512;
+constexpr int MF_T = 16;          // output tile side
+constexpr int MF_WC = 24;         // window columns (image columns w0-4 .. w0+19)
+constexpr int MF_XP = 544;        // pixel pitch of the x window planes: 17 blocks of 32; 1088 B = 64 (mod 256) keeps the
+                                  // four rows of a transposing read on disjoint banks
+constexpr int MF_MC = 32;         // mid channels per chunk
+constexpr int MF_A2P = 288;       // pixel pitch of the a2 planes (576 B = 64 mod 256)
+constexpr int MF_SP = 260;        // pixel pitch of the fp32 output stage
+
+template <int K> struct MfGeom {
+    static constexpr int P = K / 2;
+    static constexpr int HT = MF_T + 2 * P;                 // window rows
+    static constexpr int NPIX = HT * MF_WC;                 // window pixels (528 / 480 / 432)
+    static constexpr int NBLK = (NPIX + 31) / 32;           // 17 / 15 / 14
+    static constexpr int NB_WAVE = (NBLK + 7) / 8;          // pixel blocks per wave (3 / 2 / 2)
+    static constexpr int A1P = NBLK * 32 + 4;               // plane pitch: = 4 (mod 8) -> 8-byte stores of 16 planes spread over banks
+    static constexpr int NPAIR = (K + 1) / 2;               // tap pairs per kernel row and parity
+    static constexpr int TAPS = K * 2 * NPAIR;              // dwords per channel
+};
+
+template <typename T> struct Mf;
+template <> struct Mf<bf16_t> {
+    static __device__ __forceinline__ f32x16 mma(s16x8 a, s16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float dot2(uint32_t tap, uint32_t v, float acc) {
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, tap), __builtin_bit_cast(bf16x2, v), acc, false);
+    }
+};
+template <> struct Mf<f16_t> {
+    static __device__ __forceinline__ f32x16 mma(s16x8 a, s16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float dot2(uint32_t tap, uint32_t v, float acc) {
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, tap), __builtin_bit_cast(f16x2, v), acc, false);
+    }
+};
+
+// fragment of 8 k-values (rows kb .. kb+7 of a [k][pixel] LDS image with `pitch` bytes per row) of pixel column
+// pos0 + (lane & 31): lane (r, h) gets k = 16 s + 8 h + 0..7 -- the A operand (row = pixel) and the B operand
+// (column = pixel) of the 32x32x16 MFMA want exactly this.  Two transposing reads.
+__device__ __forceinline__ s16x8 mf_frag(const char* img, int pitch, int pos0, int s, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int kb = 16 * s + 8 * (g >> 1);
+    const int colb = (pos0 + 16 * (g & 1) + 4 * pp) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + (kb + q) * pitch + colb));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + (kb + 4 + q) * pitch + colb));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ int mf_acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// ---- BN folding: the per-call 16-bit operand images of the fused kernel --------------------------------------
+struct MfFold {
+    const float* w1; long long ldw1;
+    const float* w2; long long ldw2;
+    const float* f;                      // active depthwise filter [mid][K][K] (ofasr_ktransform_fwd)
+    const float* gamma[3]; const float* beta[3]; const float* mean[3]; const float* var[3];
+    float eps[3];
+    int mid, K;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) mb_fold_kernel(MfFold p, T* __restrict__ w1f, float* __restrict__ b1,
+                                                      uint32_t* __restrict__ taps, float* __restrict__ b2,
+                                                      T* __restrict__ w2f, float* __restrict__ b3) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nth = gridDim.x * blockDim.x;
+    const int mid = p.mid, K = p.K, NPAIR = (K + 1) / 2;
+    auto scale = [&](int i, int c) { return p.gamma[i][c] * rsqrtf(p.var[i][c] + p.eps[i]); };
+    for (int e = tid; e < mid * 64; e += nth) {              // expand rows scaled by BN1
+        const int c = e >> 6, k = e & 63;
+        w1f[e] = from_float<T>(p.w1[(long long)c * p.ldw1 + k] * scale(0, c));
+    }
+    for (int e = tid; e < 64 * mid; e += nth) {              // project rows scaled by BN3
+        const int o = e / mid, c = e - o * mid;
+        w2f[e] = from_float<T>(p.w2[(long long)o * p.ldw2 + c] * scale(2, o));
+    }
+    for (int c = tid; c < mid; c += nth) {
+        b1[c] = p.beta[0][c] - p.mean[0][c] * scale(0, c);
+        b2[c] = p.beta[1][c] - p.mean[1][c] * scale(1, c);
+    }
+    for (int o = tid; o < 64; o += nth) b3[o] = p.beta[2][o] - p.mean[2][o] * scale(2, o);
+    // tap pairs: per (channel, kernel row) E pairs (f0 f1)(f2 f3)..(f_{K-1} 0), then O pairs (0 f0)(f1 f2)..(f_{K-2} f_{K-1});
+    // the low half multiplies the lower window column
+    for (int e = tid; e < mid * K * 2 * NPAIR; e += nth) {
+        const int c = e / (K * 2 * NPAIR), r = e - c * (K * 2 * NPAIR);
+        const int ky = r / (2 * NPAIR), m = r - ky * 2 * NPAIR;
+        const bool odd = m >= NPAIR;
+        const int i = odd ? m - NPAIR : m;
+        const int t0 = odd ? 2 * i - 1 : 2 * i, t1 = t0 + 1;
+        const float s = scale(1, c);
+        const float* fr = p.f + ((long long)c * K + ky) * K;
+        const float lo = (t0 >= 0 && t0 < K) ? fr[t0] * s : 0.f;
+        const float hi = (t1 >= 0 && t1 < K) ? fr[t1] * s : 0.f;
+        taps[e] = (uint32_t)from_float<T>(lo).v | ((uint32_t)from_float<T>(hi).v << 16);
+    }
+}
+
+// ---- the fused block ---------------------------------------------------------------------------------------
+template <typename T, int K>
+__global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restrict__ x, T* __restrict__ out,
+                                                              const T* __restrict__ w1f, const float* __restrict__ b1,
+                                                              const uint32_t* __restrict__ taps,
+                                                              const float* __restrict__ b2, const T* __restrict__ w2f,
+                                                              const float* __restrict__ b3, int mid, int H, int W,
+                                                              int tiles_x, int tiles_y, int residual) {
+    using G = MfGeom<K>;
+    constexpr int P = G::P, HT = G::HT, NPIX = G::NPIX, NBLK = G::NBLK, NBW = G::NB_WAVE, A1P = G::A1P, NPAIR = G::NPAIR;
+    constexpr int A1_BYTES = MF_MC * A1P * 2, A2_BYTES = MF_MC * MF_A2P * 2;
+    constexpr int X_BYTES = 64 * MF_XP * 2, S_BYTES = 64 * MF_SP * 4;
+    constexpr int BODY = 2 * A1_BYTES + A2_BYTES;
+    constexpr int LDS_BYTES = BODY > X_BYTES ? (BODY > S_BYTES ? BODY : S_BYTES) : (X_BYTES > S_BYTES ? X_BYTES : S_BYTES);
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    char* Xs = lds;                      // prologue only
+    char* A1 = lds;                      // two buffers
+    char* A2 = lds + 2 * A1_BYTES;
+    float* St = reinterpret_cast<float*>(lds);   // epilogue only
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, h = lane >> 5;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x;
+    b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int h0 = ty * MF_T, w0 = tx * MF_T;
+    const long long plane = (long long)H * W;
+    const T* xn = x + (long long)n * 64 * plane;
+
+    // ---- prologue: x window -> LDS (zeros outside the image and beyond the window)
+    {
+        constexpr int QUADS = 64 * HT * (MF_WC / 4);
+        constexpr int NIT = (QUADS + MF_THREADS - 1) / MF_THREADS;
+        const bool w4 = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
+        uint2 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + it * MF_THREADS;
+            v[it] = make_uint2(0u, 0u);
+            if (e < QUADS) {
+                const int c = e / (HT * 6), rem = e - c * (HT * 6);
+                const int hh = rem / 6, qd = rem - hh * 6;
+                const int gh = h0 - P + hh, gw = w0 - 4 + 4 * qd;
+                if (gh >= 0 && gh < H) {
+                    const T* src = xn + (long long)c * plane + (long long)gh * W + gw;
+                    if (w4 && gw >= 0 && gw + 4 <= W) v[it] = *reinterpret_cast<const uint2*>(src);
+                    else {
+                        uint32_t e0 = (gw >= 0 && gw < W) ? src[0].v : 0u, e1 = (gw + 1 >= 0 && gw + 1 < W) ? src[1].v : 0u;
+                        uint32_t e2 = (gw + 2 >= 0 && gw + 2 < W) ? src[2].v : 0u, e3 = (gw + 3 >= 0 && gw + 3 < W) ? src[3].v : 0u;
+                        v[it] = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + it * MF_THREADS;
+            if (e < QUADS) {
+                const int c = e / (HT * 6), rem = e - c * (HT * 6);
+                *reinterpret_cast<uint2*>(Xs + c * (MF_XP * 2) + rem * 8) = v[it];
+            }
+        }
+        // the tail of every plane (window pixels NPIX .. XP): read by the last pixel block's fragments
+        for (int e = tid; e < 64 * ((MF_XP - NPIX) / 4); e += MF_THREADS) {
+            const int c = e / ((MF_XP - NPIX) / 4), qd = e - c * ((MF_XP - NPIX) / 4);
+            *reinterpret_cast<uint2*>(Xs + c * (MF_XP * 2) + (NPIX + 4 * qd) * 2) = make_uint2(0u, 0u);
+        }
+    }
+    __syncthreads();
+    // X fragments of this wave's pixel blocks (block pb = wave + 8 j) and the validity mask of their accumulator rows
+    s16x8 xf[NBW][4];
+    uint32_t valid[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const int pb = wave + 8 * j;
+        valid[j] = 0u;
+        if (pb < NBLK) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xf[j][s] = mf_frag(Xs, MF_XP * 2, 32 * pb, s, lane);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int px = 32 * pb + mf_acc_row(reg, h);
+                const int hh = px / MF_WC, ww = px - hh * MF_WC;
+                const int gh = h0 - P + hh, gw = w0 - 4 + ww;
+                if (px < NPIX && gh >= 0 && gh < H && gw >= 0 && gw < W) valid[j] |= 1u << reg;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xf[j][s] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    __syncthreads();   // Xs is dead from here on: A1 / A2 take its place
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[ob][i] = 0.f;
+
+    const int nchunk = mid / MF_MC;
+    const int q4 = lane & 3, row16 = lane >> 2;   // depthwise: outputs (row16, 4 q4 .. 4 q4 + 3)
+
+    auto expand = [&](int ci) {
+        const int c0 = ci * MF_MC;
+        char* dst = A1 + (ci & 1) * A1_BYTES;
+        s16x8 wf[4];
+        const T* wrow = w1f + (long long)(c0 + r32) * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wf[s] = *reinterpret_cast<const s16x8*>(wrow + 16 * s);
+        const float bias = b1[c0 + r32];
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int pb = wave + 8 * j;
+            if (pb < NBLK) {   // wave-uniform
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = Mf<T>::mma(xf[j][s], wf[s], acc);
+                char* pl = dst + r32 * (A1P * 2) + (32 * pb + 4 * h) * 2;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float a = fminf(fmaxf(acc[4 * g + i] + bias, 0.f), 6.f);
+                        v[i] = ((valid[j] >> (4 * g + i)) & 1u) ? a : 0.f;
+                    }
+                    *reinterpret_cast<uint2*>(pl + 16 * g) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+                }
+            }
+        }
+    };
+
+    auto depthwise = [&](int ci) {
+        const int c0 = ci * MF_MC;
+        const char* src = A1 + (ci & 1) * A1_BYTES;
+#pragma unroll 1
+        for (int i = 0; i < MF_MC / 8; ++i) {
+            const int cc = wave * (MF_MC / 8) + i;
+            const uint32_t* tp = taps + (long long)(c0 + cc) * G::TAPS;    // wave-uniform: scalar loads
+            const char* pl = src + cc * (A1P * 2) + (row16 * MF_WC + 4 * q4) * 2;
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const uint2 a = *reinterpret_cast<const uint2*>(pl + ky * (MF_WC * 2));
+                const uint2 bq = *reinterpret_cast<const uint2*>(pl + ky * (MF_WC * 2) + 8);
+                const uint2 cq = *reinterpret_cast<const uint2*>(pl + ky * (MF_WC * 2) + 16);
+                const uint32_t d[6] = {a.x, a.y, bq.x, bq.y, cq.x, cq.y};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int t = j + 4 - P;            // first window column of output j, relative to the lane's 12
+                    const int base = t >> 1, odd = t & 1;
+#pragma unroll
+                    for (int m = 0; m < NPAIR; ++m)
+                        o[j] = Mf<T>::dot2(tp[ky * 2 * NPAIR + odd * NPAIR + m], d[base + m], o[j]);
+                }
+            }
+            const float bias = b2[c0 + cc];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fminf(fmaxf(o[j] + bias, 0.f), 6.f);
+            *reinterpret_cast<uint2*>(A2 + cc * (MF_A2P * 2) + (row16 * MF_T + 4 * q4) * 2) =
+                make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
+        }
+    };
+
+    auto project = [&](int ci) {
+        const int c0 = ci * MF_MC;
+        s16x8 af[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) af[s] = mf_frag(A2, MF_A2P * 2, 32 * wave, s, lane);
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            const T* wrow = w2f + (long long)(32 * ob + r32) * mid + c0 + 8 * h;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                oacc[ob] = Mf<T>::mma(af[s], *reinterpret_cast<const s16x8*>(wrow + 16 * s), oacc[ob]);
+        }
+    };
+
+    // ---- chunk pipeline: [E(i) || D(i-1)] barrier [P(i-1)] barrier
+    for (int i = 0; i <= nchunk; ++i) {
+        if (wave < 4) {
+            if (i < nchunk) expand(i);
+            if (i > 0) depthwise(i - 1);
+        } else {
+            if (i > 0) depthwise(i - 1);
+            if (i < nchunk) expand(i);
+        }
+        __syncthreads();
+        if (i > 0) project(i - 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: + b3, stage fp32 [64][SP], then 16-byte row pieces (+ shortcut)
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+        const int o = 32 * ob + r32;
+        const float bias = b3[o];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(St + o * MF_SP + 32 * wave + 8 * g + 4 * h) =
+                make_float4(oacc[ob][4 * g] + bias, oacc[ob][4 * g + 1] + bias, oacc[ob][4 * g + 2] + bias,
+                            oacc[ob][4 * g + 3] + bias);
+    }
+    __syncthreads();
+    T* on = out + (long long)n * 64 * plane;
+    const bool w8 = (W & 7) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+#pragma unroll
+    for (int it = 0; it < 64 * 16 * 2 / MF_THREADS; ++it) {
+        const int e = tid + it * MF_THREADS;
+        const int half = e & 1, rr = (e >> 1) & 15, o = e >> 5;
+        const int gh = h0 + rr, gw = w0 + 8 * half;
+        if (gh >= H || gw >= W) continue;
+        const float* sp = St + o * MF_SP + rr * MF_T + 8 * half;
+        const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+        float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const long long off = (long long)o * plane + (long long)gh * W + gw;
+        if (w8 && gw + 8 <= W) {
+            if (residual) {
+                const uint4 xr = *reinterpret_cast<const uint4*>(xn + off);
+                const uint32_t xw[4] = {xr.x, xr.y, xr.z, xr.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    T lo, hi;
+                    lo.v = (uint16_t)(xw[i] & 0xffffu);
+                    hi.v = (uint16_t)(xw[i] >> 16);
+                    v[2 * i] += to_float(lo);
+                    v[2 * i + 1] += to_float(hi);
+                }
+            }
+            *reinterpret_cast<uint4*>(on + off) = make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]),
+                                                             pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
+        } else {
+            for (int i = 0; i < 8 && gw + i < W; ++i) {
+                const float xv = residual ? to_float(xn[off + i]) : 0.f;
+                on[off + i] = from_float<T>(v[i] + xv);
+            }
+        }
+    }
+}
+
+static size_t mf_align(size_t v) { return (v + 255) / 256 * 256; }
+struct MfWs {
+    size_t f, w1f, b1, taps, b2, w2f, b3, total;
+};
+static MfWs mf_ws(int64_t mid, int K) {
+    MfWs s;
+    const int npair = (K + 1) / 2;
+    size_t o = 0;
+    s.f = o;    o += mf_align((size_t)mid * K * K * sizeof(float));
+    s.w1f = o;  o += mf_align((size_t)mid * 64 * 2);
+    s.b1 = o;   o += mf_align((size_t)mid * sizeof(float));
+    s.taps = o; o += mf_align((size_t)mid * K * 2 * npair * sizeof(uint32_t));
+    s.b2 = o;   o += mf_align((size_t)mid * sizeof(float));
+    s.w2f = o;  o += mf_align((size_t)64 * mid * 2);
+    s.b3 = o;   o += mf_align(64 * sizeof(float));
+    s.total = o;
+    return s;
+}
+
+static bool mf_supported(const ofasr_mbconv_desc* d) {
+    return d && (d->dtype == OFASR_BF16 || d->dtype == OFASR_F16) && d->Cin == 64 && d->Cout == 64 && d->mid > 0 &&
+           d->mid % MF_MC == 0 && (d->K == 3 || d->K == 5 || d->K == 7) && !d->bn_training[0] && !d->bn_training[1] &&
+           !d->bn_training[2] && d->N > 0 && d->H > 0 && d->W > 0;
+}
+
+template <typename T>
+static int mf_launch(const ofasr_mbconv_desc* d, const void* x, void* out, char* ws, const MfWs& s, hipStream_t st) {
+    MfFold p;
+    p.w1 = d->w1; p.ldw1 = d->ldw1; p.w2 = d->w2; p.ldw2 = d->ldw2;
+    p.f = reinterpret_cast<const float*>(ws + s.f);
+    for (int i = 0; i < 3; ++i) {
+        p.gamma[i] = d->gamma[i]; p.beta[i] = d->beta[i]; p.mean[i] = d->running_mean[i]; p.var[i] = d->running_var[i];
+        p.eps[i] = (float)d->bn_eps[i];
+    }
+    p.mid = (int)d->mid; p.K = d->K;
+    T* w1f = reinterpret_cast<T*>(ws + s.w1f);
+    T* w2f = reinterpret_cast<T*>(ws + s.w2f);
+    float* b1 = reinterpret_cast<float*>(ws + s.b1);
+    float* b2 = reinterpret_cast<float*>(ws + s.b2);
+    float* b3 = reinterpret_cast<float*>(ws + s.b3);
+    uint32_t* taps = reinterpret_cast<uint32_t*>(ws + s.taps);
+    OFASR_LAUNCH((mb_fold_kernel<T>), dim3(96), dim3(256), 0, st, p, w1f, b1, taps, b2, w2f, b3);
+    int rc = check_launch("ofasr_mbconv_infer");
+    if (rc) return rc;
+    const int tiles_x = (int)cdiv(d->W, MF_T), tiles_y = (int)cdiv(d->H, MF_T);
+    const long long blocks = (long long)d->N * tiles_x * tiles_y;
+    OFASR_REQUIRE(blocks <= INT32_MAX, OFASR_ERR_UNSUPPORTED, "ofasr_mbconv_infer: too many tiles");
+    const double px = (double)d->N * (double)d->H * (double)d->W;
+    prof_note(2.0 * px * 64 * (d->residual ? 3.0 : 2.0), 2.0 * px * (2.0 * 64 * d->mid + (double)d->K * d->K * d->mid));
+#define OFASR_MF(KK)                                                                                                \
+    OFASR_LAUNCH((mb_fused_kernel<T, KK>), dim3((unsigned)blocks), dim3(MF_THREADS), 0, st, (const T*)x, (T*)out, \
+                 (const T*)w1f, (const float*)b1, (const uint32_t*)taps, (const float*)b2, (const T*)w2f,          \
+                 (const float*)b3, (int)d->mid, (int)d->H, (int)d->W, tiles_x, tiles_y, d->residual)
+    if (d->K == 7) OFASR_MF(7);
+    else if (d->K == 5) OFASR_MF(5);
+    else OFASR_MF(3);
+#undef OFASR_MF
+    return check_launch("ofasr_mbconv_infer");
+}
+
+}  // namespace ofasr
+
+using namespace ofasr;
+
+OFASR_EXPORT int ofasr_mbconv_infer_supported(const ofasr_mbconv_desc* d) { return mf_supported(d) ? 1 : 0; }
+
+OFASR_EXPORT size_t ofasr_mbconv_infer_workspace(const ofasr_mbconv_desc* d) {
+    if (!mf_supported(d)) return 0;
+    return mf_ws(d->mid, d->K).total;
+}
+
+OFASR_EXPORT int ofasr_mbconv_infer(const ofasr_mbconv_desc* d, const void* x, void* out, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    const char* name = "ofasr_mbconv_infer";
+    OFASR_REQUIRE(d && x && out, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(mf_supported(d), OFASR_ERR_UNSUPPORTED,
+                  "%s: needs eval-mode BN, 16-bit activations, 64 -> mid (multiple of 32) -> 64 channels, K in {3,5,7}", name);
+    OFASR_REQUIRE(d->w1 && d->w2 && d->wdw_max, OFASR_ERR_INVALID_ARG, "%s: null weight", name);
+    for (int i = 0; i < 3; ++i)
+        OFASR_REQUIRE(d->gamma[i] && d->beta[i] && d->running_mean[i] && d->running_var[i], OFASR_ERR_INVALID_ARG,
+                      "%s: null BN tensor %d", name, i);
+    OFASR_REQUIRE(d->chain_len >= 1 && d->chain_len <= 4 && d->ks[d->chain_len - 1] == d->K, OFASR_ERR_INVALID_ARG,
+                  "%s: bad kernel chain", name);
+    const MfWs s = mf_ws(d->mid, d->K);
+    OFASR_REQUIRE(workspace && workspace_bytes >= s.total, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", name,
+                  workspace_bytes, s.total);
+    char* ws = (char*)workspace;
+    int rc = ofasr_ktransform_fwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform,
+                                  reinterpret_cast<float*>(ws + s.f), d->mid, stream);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    if (d->dtype == OFASR_F16) return mf_launch<f16_t>(d, x, out, ws, s, st);
+    return mf_launch<bf16_t>(d, x, out, ws, s, st);
+}

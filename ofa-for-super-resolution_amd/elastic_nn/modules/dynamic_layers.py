@@ -97,6 +97,13 @@ class DynamicMBConvLayer(MyModule):
         bn1, bn2, bn3 = self.inverted_bottleneck.bn.bn, self.depth_conv.bn.bn, self.point_linear.bn.bn
         cfg = {"mid": self.active_middle_channel(x.size(1)), "out": self.active_out_channel, "K": K, "chain": chain,
                "residual": add_x, "bns": (bn1, bn2, bn3)}
+        if ops.FUSED_INFER and not torch.is_grad_enabled() and not (bn1.training or bn2.training or bn3.training) \
+                and (add_x or residual is None):
+            # inference with eval-mode BN: the block is one kernel (BN folded, the mid tensor never reaches HBM)
+            y = ops.mbconv_infer(x, cfg, self.inverted_bottleneck.conv.conv.weight, bn1.weight, bn1.bias, dw.conv.weight,
+                                 bn2.weight, bn2.bias, self.point_linear.conv.conv.weight, bn3.weight, bn3.bias, *mats)
+            if y is not None:
+                return y
         y = ops.FusedMBConvFn.apply(x, cfg, self.inverted_bottleneck.conv.conv.weight, bn1.weight, bn1.bias,
                                     dw.conv.weight, bn2.weight, bn2.bias, self.point_linear.conv.conv.weight,
                                     bn3.weight, bn3.bias, *mats)

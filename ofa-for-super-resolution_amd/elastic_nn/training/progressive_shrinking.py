@@ -20,7 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from ...imagenet_codebase.run_manager.sr_run_manager import SRRunManager  # noqa: F401
-from ...utils import AverageMeter, int2list, list_mean, psnr_y_device, subset_mean
+from ...utils import AverageMeter, device_batch, int2list, list_mean, psnr_y_device, subset_mean
 
 
 def validate(run_manager, epoch=0, is_test=True, image_size_list=None, width_mult_list=None, ks_list=None,
@@ -97,9 +97,8 @@ def train_one_epoch(run_manager, args, epoch, warmup_epochs=0, warmup_lr=0):
                 run_manager.optimizer, warmup_epochs * nBatch, nBatch, epoch, i, warmup_lr)
         else:
             new_lr = run_manager.run_config.adjust_learning_rate(run_manager.optimizer, epoch - warmup_epochs, i, nBatch)
-        images = mini_batch["image"].to(dev, non_blocking=True)
-        x2 = mini_batch["2x_down_image"].to(dev, non_blocking=True)
-        x4 = mini_batch["4x_down_image"].to(dev, non_blocking=True)
+        mini_batch = device_batch(mini_batch, dev)     # LR images made on the GPU when the loader ships uint8 HR only
+        images, x2, x4 = mini_batch["image"], mini_batch["2x_down_image"], mini_batch["4x_down_image"]
 
         soft_logits = None
         if args.kd_ratio > 0:

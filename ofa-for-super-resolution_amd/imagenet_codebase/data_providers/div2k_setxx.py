@@ -157,9 +157,10 @@ class Div2K_SetXXDataset(torch.utils.data.Dataset):
     """reference :288-298.  `samples` aliases `paths` (the reference's provider reads `dataset.samples`, an
     ImageFolder attribute its own dataset class does not define -- :51,57,206)."""
 
-    def __init__(self, root_dir, transform=None):
+    def __init__(self, root_dir, transform=None, lr_on_device=False):
         self.root_dir = root_dir
         self.transform = transform
+        self.lr_on_device = lr_on_device   # yield only the uint8 HR image; the LR images are made on the GPU
         self.paths = get_image_paths_recursive(self.root_dir, [])
         self.samples = self.paths
         self.size = len(self.paths)
@@ -170,6 +171,9 @@ class Div2K_SetXXDataset(torch.utils.data.Dataset):
     def __getitem__(self, index):
         img = Image.open(self.paths[index]).convert("RGB")
         H_img = self.transform(img) if self.transform is not None else img
+        if self.lr_on_device:   # 1/4 of the float bytes cross PCIe; ops.lr_images_from_u8 does the PIL bicubic on the GPU
+            a = np.asarray(H_img, dtype=np.uint8)
+            return {"image_u8": torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))}
         L2_img = get_transform_L(opt=2)(H_img)
         L4_img = get_transform_L(opt=4)(H_img)
         return {"image": to_tensor(H_img), "2x_down_image": to_tensor(L2_img), "4x_down_image": to_tensor(L4_img)}
@@ -239,8 +243,10 @@ class Div2K_SetXXDataProvider(DataProvider):
     DEFAULT_PATH = "/SSD/div2k_setxx"
 
     def __init__(self, save_path=None, train_batch_size=256, test_batch_size=512, valid_size=None, n_worker=32,
-                 resize_scale=0.08, distort_color=None, image_size=32, num_replicas=None, rank=None):
+                 resize_scale=0.08, distort_color=None, image_size=32, num_replicas=None, rank=None,
+                 lr_on_device=False):
         warnings.filterwarnings("ignore")
+        self.lr_on_device = bool(lr_on_device)
         if Image is None:
             raise ImportError("Div2K_SetXXDataProvider needs PIL")
         self._save_path = save_path
@@ -310,10 +316,10 @@ class Div2K_SetXXDataProvider(DataProvider):
         return os.path.join(self.save_path, "val")
 
     def train_dataset(self, _transforms):
-        return Div2K_SetXXDataset(self.train_path, _transforms)
+        return Div2K_SetXXDataset(self.train_path, _transforms, lr_on_device=getattr(self, "lr_on_device", False))
 
     def test_dataset(self, _transforms):
-        return Div2K_SetXXDataset(self.valid_path, _transforms)
+        return Div2K_SetXXDataset(self.valid_path, _transforms, lr_on_device=getattr(self, "lr_on_device", False))
 
     def build_train_transform(self, image_size=None, print_log=True):
         """RandomCrop -> RandomHorizontalFlip -> RandomRotation((-90, 90)) (reference :145-180; its resizing crop and

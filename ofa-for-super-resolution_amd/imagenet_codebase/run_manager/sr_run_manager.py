@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from ... import distributed as dd
-from ...utils import AverageMeter, bucket_by_size, psnr_y, psnr_y_per_image
+from ...utils import AverageMeter, bucket_by_size, device_batch, psnr_y, psnr_y_per_image
 from ..utils import get_net_info
 
 
@@ -283,8 +283,8 @@ class SRRunManager(object):
         losses, psnrs = AverageMeter(), AverageMeter()
         with torch.no_grad():
             for mini_batch in data_loader:
-                images = mini_batch["image"].to(self.device)
-                lr = mini_batch[input_key].to(self.device)
+                mini_batch = device_batch(mini_batch, self.device)
+                images, lr = mini_batch["image"], mini_batch[input_key]
                 with self.autocast():
                     output = net(lr)
                 output = output.float()
@@ -305,6 +305,7 @@ class SRRunManager(object):
         net.eval()
         items = []
         for mini_batch in data_loader:
+            mini_batch = device_batch(mini_batch, self.device)
             for i in range(mini_batch["image"].shape[0]):
                 items.append({k: v[i:i + 1] for k, v in mini_batch.items() if torch.is_tensor(v)})
         losses, psnrs, calls = AverageMeter(), AverageMeter(), 0
@@ -343,8 +344,8 @@ class SRRunManager(object):
                                                                      epoch, i, warmup_lr)
             else:
                 new_lr = self.run_config.adjust_learning_rate(self.optimizer, epoch - warmup_epochs, i, nBatch)
-            images = mini_batch["image"].to(self.device)
-            lr_img = mini_batch[input_key].to(self.device)
+            mini_batch = device_batch(mini_batch, self.device)
+            images, lr_img = mini_batch["image"], mini_batch[input_key]
             with self.autocast():
                 output = self.net(lr_img)
             output = output.float()

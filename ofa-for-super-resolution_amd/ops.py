@@ -153,6 +153,37 @@ def pixel_unshuffle(x, r=2):
     return PixelUnshuffleFn.apply(x, r)
 
 
+# ------------------------------------------------------------------------- PIL-exact bicubic LR images
+def bicubic_resize_u8(img, out_h, out_w):
+    """uint8 [..., H, W] planes on the GPU -> [..., out_h, out_w], bit-identical to PIL's
+    Image.resize((out_w, out_h), Image.BICUBIC) per plane (ofasr_bicubic_resize_u8, csrc/resample.hip)."""
+    _gpu(img)
+    if img.dtype != torch.uint8:
+        raise _C.OfasrError("bicubic_resize_u8 works on uint8 images (the reference resizes before ToTensor), got %s" % img.dtype)
+    img = img.contiguous()
+    H, W = img.shape[-2:]
+    planes = img.numel() // (H * W)
+    out = torch.empty(tuple(img.shape[:-2]) + (out_h, out_w), dtype=torch.uint8, device=img.device)
+    L = _C.lib()
+    wst, wsp, wsn = _ws(L.ofasr_bicubic_resize_u8_workspace(planes, H, W, out_h, out_w), img.device)
+    with _timed("bicubic_resize_u8", img.numel() + out.numel()):
+        _C.check(L.ofasr_bicubic_resize_u8(_p(img), _p(out), planes, H, W, out_h, out_w, wsp, wsn, _stream()),
+                 "bicubic_resize_u8")
+    return out
+
+
+def lr_images_from_u8(hr_u8):
+    """{'image', '2x_down_image', '4x_down_image'} (float32 in [0, 1], the loader contract of the reference's
+    Div2K_SetXXDataset.__getitem__, div2k_setxx.py:288-298) from a uint8 HR batch [N, 3, H, W] already on the GPU:
+    Scale(1/2) and Scale(1/4) as PIL computes them (output size int(h/f) x int(w/f)), then ToTensor's /255."""
+    _, _, H, W = hr_u8.shape
+    out = {"image": hr_u8.float().div_(255.0)}
+    for f in (2, 4):
+        lr = bicubic_resize_u8(hr_u8, int(H * (1.0 / f)), int(W * (1.0 / f)))
+        out["%dx_down_image" % f] = lr.float().div_(255.0)
+    return out
+
+
 # --------------------------------------------------------------------------- kernel transform
 def _kt_args(chain, mats):
     ks = (ctypes.c_int * len(chain))(*chain)
@@ -493,6 +524,61 @@ def _defer_this_backward(params):
     return True
 
 
+def _mbconv_desc(x, cfg, w1, g1, b1, wdw, g2, b2, w2, g3, b3, mats):
+    """ofasr_mbconv_desc of one block call (include/ofasr.h) from the host mirror's tensors"""
+    N, Cin, H, W = x.shape
+    d = _C.MBConvDesc()
+    d.N, d.Cin, d.mid, d.Cout, d.H, d.W = N, Cin, cfg["mid"], cfg["out"], H, W
+    d.K = cfg["K"]
+    for i, k in enumerate(cfg["chain"]):
+        d.ks[i] = k
+    d.chain_len = len(cfg["chain"])
+    d.transform = 1 if mats else 0
+    d.dtype = _dt(x)
+    d.residual = 1 if cfg["residual"] else 0
+    gam, bet = (g1, g2, g3), (b1, b2, b3)
+    for i, bn in enumerate(cfg["bns"]):
+        training = bn.training or not bn.track_running_stats
+        d.bn_training[i] = 1 if training else 0
+        upd = bn.training and bn.track_running_stats
+        d.bn_momentum[i] = float(bn.momentum) if upd else 0.0
+        d.bn_eps[i] = float(bn.eps)
+        d.gamma[i] = gam[i].data_ptr()
+        d.beta[i] = bet[i].data_ptr()
+        d.running_mean[i] = bn.running_mean.data_ptr()
+        d.running_var[i] = bn.running_var.data_ptr()
+        d.num_batches_tracked[i] = bn.num_batches_tracked.data_ptr() if (upd and bn.num_batches_tracked is not None) else None
+    d.Cmid_max, d.Cout_max = w1.shape[0], w2.shape[0]
+    d.ldw1, d.ldw2 = w1.shape[1], w2.shape[1]
+    d.w1, d.w2, d.wdw_max = w1.data_ptr(), w2.data_ptr(), wdw.data_ptr()
+    for i, m in enumerate(mats):
+        d.mats[i] = m.data_ptr()
+    return d
+
+
+FUSED_INFER = os.environ.get("OFASR_MBCONV_FUSED_INFER", "1") != "0"   # the one-kernel eval-mode block (ofasr_mbconv_infer)
+
+
+def mbconv_infer(x, cfg, w1, g1, b1, wdw, g2, b2, w2, g3, b3, *mats):
+    """the whole MB block (+ shortcut) as ONE kernel, forward only, eval-mode BN folded into the convolutions
+    (ofasr_mbconv_infer, csrc/mbfused.hip).  Returns None when the shape / dtype / BN mode is outside what the kernel
+    implements (the caller then takes the composite path)."""
+    _gpu(x, w1, wdw, w2)
+    if x.dtype not in (torch.float16, torch.bfloat16):
+        return None
+    x = x.contiguous()
+    L = _C.lib()
+    d = _mbconv_desc(x, cfg, w1, g1, b1, wdw, g2, b2, w2, g3, b3, mats)
+    dp = ctypes.byref(d)
+    if not L.ofasr_mbconv_infer_supported(dp):
+        return None
+    out = torch.empty((x.shape[0], cfg["out"], x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device)
+    wst, wsp, wsn = _ws(L.ofasr_mbconv_infer_workspace(dp), x.device)
+    with _timed("mbconv_infer"):
+        _C.check(L.ofasr_mbconv_infer(dp, _p(x), _p(out), wsp, wsn, _stream()), "mbconv_infer")
+    return out
+
+
 class FusedMBConvFn(Function):
     """DynamicMBConvLayer.forward (+ identity shortcut) as ONE host call per direction (ofasr_mbconv_fwd/_bwd,
     include/ofasr.h): expand 1x1 -> BN+ReLU6 -> kernel transform -> depthwise -> BN+ReLU6 -> project 1x1 -> BN (+x).
@@ -509,34 +595,9 @@ class FusedMBConvFn(Function):
         x = x.contiguous()
         L = _C.lib()
         N, Cin, H, W = x.shape
-        mid, Cout, K, chain = cfg["mid"], cfg["out"], cfg["K"], cfg["chain"]
-        d = _C.MBConvDesc()
-        d.N, d.Cin, d.mid, d.Cout, d.H, d.W = N, Cin, mid, Cout, H, W
-        d.K = K
-        for i, k in enumerate(chain):
-            d.ks[i] = k
-        d.chain_len = len(chain)
-        d.transform = 1 if mats else 0
-        d.dtype = _dt(x)
-        d.residual = 1 if cfg["residual"] else 0
+        mid, Cout = cfg["mid"], cfg["out"]
         bns = cfg["bns"]
-        gam, bet = (g1, g2, g3), (b1, b2, b3)
-        for i, bn in enumerate(bns):
-            training = bn.training or not bn.track_running_stats
-            d.bn_training[i] = 1 if training else 0
-            upd = bn.training and bn.track_running_stats
-            d.bn_momentum[i] = float(bn.momentum) if upd else 0.0
-            d.bn_eps[i] = float(bn.eps)
-            d.gamma[i] = gam[i].data_ptr()
-            d.beta[i] = bet[i].data_ptr()
-            d.running_mean[i] = bn.running_mean.data_ptr()
-            d.running_var[i] = bn.running_var.data_ptr()
-            d.num_batches_tracked[i] = bn.num_batches_tracked.data_ptr() if (upd and bn.num_batches_tracked is not None) else None
-        d.Cmid_max, d.Cout_max = w1.shape[0], w2.shape[0]
-        d.ldw1, d.ldw2 = w1.shape[1], w2.shape[1]
-        d.w1, d.w2, d.wdw_max = w1.data_ptr(), w2.data_ptr(), wdw.data_ptr()
-        for i, m in enumerate(mats):
-            d.mats[i] = m.data_ptr()
+        d = _mbconv_desc(x, cfg, w1, g1, b1, wdw, g2, b2, w2, g3, b3, mats)
         dp = ctypes.byref(d)
         HW = H * W
         act = torch.empty(N * HW * (4 * mid + 2 * Cout), dtype=x.dtype, device=x.device)

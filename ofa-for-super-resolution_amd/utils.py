@@ -218,6 +218,15 @@ def bucket_by_size(items, key=None, max_batch=None):
     return [chunk for shp in order for chunk in groups[shp]]
 
 
+def device_batch(mini_batch, device):
+    """a loader batch on `device` under the reference's keys.  Batches of a provider built with lr_on_device=True carry
+    only 'image_u8' (uint8 HR): the LR images are then made on the GPU with PIL's exact bicubic arithmetic
+    (ops.lr_images_from_u8) instead of by the host-side PIL calls of div2k_setxx.py:288-298."""
+    if "image_u8" in mini_batch:
+        return ops.lr_images_from_u8(mini_batch["image_u8"].to(device, non_blocking=True))
+    return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in mini_batch.items()}
+
+
 class AverageMeter(object):
     """reference ofa/utils.py:53-75"""
 

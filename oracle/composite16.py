@@ -94,3 +94,37 @@ def depthwise_fwd(a1, f, dtype, mma):
 
 def project_fwd(a2, w2_full, cout, dtype):
     return oracle.pwconv_fwd(r16(a2, dtype), r16(w2_full, dtype), cout)
+
+
+# ------------------------------------------------------------------- the eval-mode block with BN folded (one kernel)
+def folded_operands(w1_full, f, w2_full, bn, mid, dtype, eps=1e-5):
+    """the operands ofasr_mbconv_infer computes with: eval-mode BN i is y -> y*s_i + t_i with
+    s = gamma / sqrt(running_var + eps), t = beta - running_mean * s (dynamic_op.py:148-167 in eval mode), folded into
+    the rows of the 1x1 weights and into the depthwise taps, 16-bit operands / fp32 biases.
+    bn: {0,1,2: {weight, bias, running_mean, running_var}}; f: active filter [mid,1,K,K]."""
+    def st(i, C):
+        s = bn[i]["weight"][:C].astype(np.float64) / np.sqrt(bn[i]["running_var"][:C].astype(np.float64) + eps)
+        return s.astype(np.float32), (bn[i]["bias"][:C].astype(np.float64) - bn[i]["running_mean"][:C] * s).astype(np.float32)
+
+    s1, t1 = st(0, mid)
+    s2, t2 = st(1, mid)
+    cout = w2_full.shape[0]
+    s3, t3 = st(2, cout)
+    cin = w1_full.shape[1]
+    w1f = r16(w1_full[:mid, :cin, 0, 0] * s1[:, None], dtype)
+    ff = r16(np.asarray(f, np.float32).reshape(mid, -1) * s2[:, None], dtype).reshape(np.asarray(f).shape)
+    w2f = r16(w2_full[:cout, :mid, 0, 0] * s3[:, None], dtype)
+    return w1f, t1, ff, t2, w2f, t3
+
+
+def fused_eval_block(x16, w1_full, f, w2_full, bn, mid, dtype, residual=True):
+    """restatement of the fused eval-mode block with the C oracle's operators (double accumulation): 16-bit a1 / a2
+    (they are matrix-core / dot-product operands), fp32 everywhere else, one rounding of the output."""
+    w1f, t1, ff, t2, w2f, t3 = folded_operands(w1_full, f, w2_full, bn, mid, dtype)
+    y1 = oracle.pwconv_fwd(x16, w1f.reshape(mid, -1, 1, 1), mid) + t1.reshape(1, mid, 1, 1)
+    a1 = r16(np.clip(y1, RELU6_LO, RELU6_HI), dtype)
+    y2 = oracle.dwconv_fwd(a1, ff) + t2.reshape(1, mid, 1, 1)
+    a2 = r16(np.clip(y2, RELU6_LO, RELU6_HI), dtype)
+    cout = w2f.shape[0]
+    y3 = oracle.pwconv_fwd(a2, w2f.reshape(cout, mid, 1, 1), cout) + t3.reshape(1, cout, 1, 1)
+    return r16(y3.astype(np.float64) + (x16 if residual else 0.0), dtype)
