@@ -59,7 +59,8 @@ template <int K> struct MfGeom {
     static constexpr int NB_WAVE = (NBLK + 7) / 8;          // pixel blocks per wave (3 / 2 / 2)
     static constexpr int A1P = NBLK * 32 + 4;               // plane pitch: = 4 (mod 8) -> 8-byte stores of 16 planes spread over banks
     static constexpr int NPAIR = (K + 1) / 2;               // tap pairs per kernel row and parity
-    static constexpr int TAPS = K * 2 * NPAIR;              // dwords per channel
+    static constexpr int TAPS = K * 2 * NPAIR;              // tap-pair dwords per channel
+    static constexpr int TAPROW = (TAPS + 1 + 3) / 4 * 4;   // + the BN2 bias, padded: one scalar-load row per channel
 };
 
 template <typename T> struct Mf;
@@ -111,17 +112,25 @@ __global__ void __launch_bounds__(256) mb_fold_kernel(MfFold p, T* __restrict__ 
     const int nth = gridDim.x * blockDim.x;
     const int mid = p.mid, K = p.K, NPAIR = (K + 1) / 2;
     auto scale = [&](int i, int c) { return p.gamma[i][c] * rsqrtf(p.var[i][c] + p.eps[i]); };
-    for (int e = tid; e < mid * 64; e += nth) {              // expand rows scaled by BN1
-        const int c = e >> 6, k = e & 63;
+    // Weight images in MFMA-fragment order: the 16 bytes lane l of a wave needs for (chunk, k-step) sit at
+    // [(chunk, s)][l], so a fragment load is one fully coalesced 1 KB request.
+    //   w1f[((ci*4 + s)*64 + l)*8 + j] = s1[c] * W1[c][16 s + 8 (l>>5) + j],          c = 32 ci + (l & 31)
+    //   w2f[(((ci*2 + ob)*2 + s)*64 + l)*8 + j] = s3[o] * W2[o][32 ci + 16 s + 8 (l>>5) + j],  o = 32 ob + (l & 31)
+    for (int e = tid; e < mid * 64; e += nth) {
+        const int j = e & 7, l = (e >> 3) & 63, s4 = (e >> 9) & 3, ci = e >> 11;
+        const int c = 32 * ci + (l & 31), k = 16 * s4 + 8 * (l >> 5) + j;
         w1f[e] = from_float<T>(p.w1[(long long)c * p.ldw1 + k] * scale(0, c));
     }
-    for (int e = tid; e < 64 * mid; e += nth) {              // project rows scaled by BN3
-        const int o = e / mid, c = e - o * mid;
+    for (int e = tid; e < 64 * mid; e += nth) {
+        const int j = e & 7, l = (e >> 3) & 63, s2 = (e >> 9) & 1, ob = (e >> 10) & 1, ci = e >> 11;
+        const int o = 32 * ob + (l & 31), c = 32 * ci + 16 * s2 + 8 * (l >> 5) + j;
         w2f[e] = from_float<T>(p.w2[(long long)o * p.ldw2 + c] * scale(2, o));
     }
+    const int TAPROW = (K * 2 * NPAIR + 1 + 3) / 4 * 4;
     for (int c = tid; c < mid; c += nth) {
         b1[c] = p.beta[0][c] - p.mean[0][c] * scale(0, c);
         b2[c] = p.beta[1][c] - p.mean[1][c] * scale(1, c);
+        taps[(long long)c * TAPROW + K * 2 * NPAIR] = __float_as_uint(b2[c]);   // the row's last word: BN2 bias
     }
     for (int o = tid; o < 64; o += nth) b3[o] = p.beta[2][o] - p.mean[2][o] * scale(2, o);
     // tap pairs: per (channel, kernel row) E pairs (f0 f1)(f2 f3)..(f_{K-1} 0), then O pairs (0 f0)(f1 f2)..(f_{K-2} f_{K-1});
@@ -136,7 +145,7 @@ __global__ void __launch_bounds__(256) mb_fold_kernel(MfFold p, T* __restrict__ 
         const float* fr = p.f + ((long long)c * K + ky) * K;
         const float lo = (t0 >= 0 && t0 < K) ? fr[t0] * s : 0.f;
         const float hi = (t1 >= 0 && t1 < K) ? fr[t1] * s : 0.f;
-        taps[e] = (uint32_t)from_float<T>(lo).v | ((uint32_t)from_float<T>(hi).v << 16);
+        taps[(long long)c * TAPROW + r] = (uint32_t)from_float<T>(lo).v | ((uint32_t)from_float<T>(hi).v << 16);
     }
 }
 
@@ -178,32 +187,45 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
         constexpr int QUADS = 64 * HT * (MF_WC / 4);
         constexpr int NIT = (QUADS + MF_THREADS - 1) / MF_THREADS;
         const bool w4 = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
-        uint2 v[NIT];
+        if (w4) {
+            // every quad is wholly inside or outside the image: request ALL of them from clamped (always valid)
+            // addresses as straight-line code, zero the outside ones afterwards -- a load under a lane-dependent
+            // branch would end its basic block with s_waitcnt vmcnt(0): 17 serial round trips instead of one
+            uint2 v[NIT];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = tid + it * MF_THREADS;
-            v[it] = make_uint2(0u, 0u);
-            if (e < QUADS) {
+            for (int it = 0; it < NIT; ++it) {
+                const int e0 = tid + it * MF_THREADS;
+                const int e = e0 < QUADS ? e0 : QUADS - 1;
                 const int c = e / (HT * 6), rem = e - c * (HT * 6);
                 const int hh = rem / 6, qd = rem - hh * 6;
                 const int gh = h0 - P + hh, gw = w0 - 4 + 4 * qd;
-                if (gh >= 0 && gh < H) {
-                    const T* src = xn + (long long)c * plane + (long long)gh * W + gw;
-                    if (w4 && gw >= 0 && gw + 4 <= W) v[it] = *reinterpret_cast<const uint2*>(src);
-                    else {
-                        uint32_t e0 = (gw >= 0 && gw < W) ? src[0].v : 0u, e1 = (gw + 1 >= 0 && gw + 1 < W) ? src[1].v : 0u;
-                        uint32_t e2 = (gw + 2 >= 0 && gw + 2 < W) ? src[2].v : 0u, e3 = (gw + 3 >= 0 && gw + 3 < W) ? src[3].v : 0u;
-                        v[it] = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
-                    }
+                const int ghc = gh < 0 ? 0 : (gh >= H ? H - 1 : gh), gwc = gw < 0 ? 0 : (gw + 4 > W ? W - 4 : gw);
+                v[it] = *reinterpret_cast<const uint2*>(xn + (long long)c * plane + (long long)ghc * W + gwc);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = tid + it * MF_THREADS;
+                if (e < QUADS) {
+                    const int c = e / (HT * 6), rem = e - c * (HT * 6);
+                    const int hh = rem / 6, qd = rem - hh * 6;
+                    const int gh = h0 - P + hh, gw = w0 - 4 + 4 * qd;
+                    const bool ok = gh >= 0 && gh < H && gw >= 0 && gw + 4 <= W;
+                    *reinterpret_cast<uint2*>(Xs + c * (MF_XP * 2) + rem * 8) = ok ? v[it] : make_uint2(0u, 0u);
                 }
             }
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = tid + it * MF_THREADS;
-            if (e < QUADS) {
+        } else {   // ragged width / unaligned base: element-wise guarded loads straight into the LDS image
+            for (int e = tid; e < QUADS; e += MF_THREADS) {
                 const int c = e / (HT * 6), rem = e - c * (HT * 6);
-                *reinterpret_cast<uint2*>(Xs + c * (MF_XP * 2) + rem * 8) = v[it];
+                const int hh = rem / 6, qd = rem - hh * 6;
+                const int gh = h0 - P + hh, gw = w0 - 4 + 4 * qd;
+                uint2 q = make_uint2(0u, 0u);
+                if (gh >= 0 && gh < H) {
+                    const T* src = xn + (long long)c * plane + (long long)gh * W + gw;
+                    const uint32_t e0 = (gw >= 0 && gw < W) ? src[0].v : 0u, e1 = (gw + 1 >= 0 && gw + 1 < W) ? src[1].v : 0u;
+                    const uint32_t e2 = (gw + 2 >= 0 && gw + 2 < W) ? src[2].v : 0u, e3 = (gw + 3 >= 0 && gw + 3 < W) ? src[3].v : 0u;
+                    q = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
+                }
+                *reinterpret_cast<uint2*>(Xs + c * (MF_XP * 2) + rem * 8) = q;
             }
         }
         // the tail of every plane (window pixels NPIX .. XP): read by the last pixel block's fragments
@@ -213,26 +235,29 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
         }
     }
     __syncthreads();
-    // X fragments of this wave's pixel blocks (block pb = wave + 8 j) and the validity mask of their accumulator rows
+    // X fragments of this wave's pixel blocks (block pb = wave + 8 j) and, per block, the 16-bit AND masks of its 8 packed
+    // output words (positions outside the image / beyond the window are forced to zero after the activation).  Masks are
+    // VGPR data on purpose: as predicates the compiler keeps 16 lane masks per block in SGPR pairs and spills them.
     s16x8 xf[NBW][4];
-    uint32_t valid[NBW];
+    uint32_t mk[NBW][8];
 #pragma unroll
     for (int j = 0; j < NBW; ++j) {
         const int pb = wave + 8 * j;
-        valid[j] = 0u;
-        if (pb < NBLK) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) xf[j][s] = mf_frag(Xs, MF_XP * 2, 32 * pb, s, lane);
+        for (int s = 0; s < 4; ++s)
+            xf[j][s] = pb < NBLK ? mf_frag(Xs, MF_XP * 2, 32 * (pb < NBLK ? pb : 0), s, lane) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
+        for (int wd = 0; wd < 8; ++wd) {
+            uint32_t m = 0u;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int reg = 2 * wd + e;
                 const int px = 32 * pb + mf_acc_row(reg, h);
                 const int hh = px / MF_WC, ww = px - hh * MF_WC;
                 const int gh = h0 - P + hh, gw = w0 - 4 + ww;
-                if (px < NPIX && gh >= 0 && gh < H && gw >= 0 && gw < W) valid[j] |= 1u << reg;
+                if (px < NPIX && gh >= 0 && gh < H && gw >= 0 && gw < W) m |= 0xffffu << (16 * e);
             }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) xf[j][s] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            mk[j][wd] = m;
         }
     }
     __syncthreads();   // Xs is dead from here on: A1 / A2 take its place
@@ -245,34 +270,49 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
 
     const int nchunk = mid / MF_MC;
     const int q4 = lane & 3, row16 = lane >> 2;   // depthwise: outputs (row16, 4 q4 .. 4 q4 + 3)
+    const s16x8* w1q = reinterpret_cast<const s16x8*>(w1f) + lane;   // fragment-ordered images: [(chunk, s)][lane]
+    const s16x8* w2q = reinterpret_cast<const s16x8*>(w2f) + lane;
 
-    auto expand = [&](int ci) {
-        const int c0 = ci * MF_MC;
-        char* dst = A1 + (ci & 1) * A1_BYTES;
-        s16x8 wf[4];
-        const T* wrow = w1f + (long long)(c0 + r32) * 64 + 8 * h;
+    // operands: the expand fragments of chunk i+1 are requested at the top of iteration i (a whole chunk ahead); the
+    // project fragments of chunk i-1 at the top of iteration i, i.e. a whole expand/depthwise phase before their use
+    struct W1 {
+        s16x8 w[4];
+        float bias;
+    };
+    struct W2 {
+        s16x8 w[2][2];
+    };
+    auto load_w1 = [&](int ci, W1& cw) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wf[s] = *reinterpret_cast<const s16x8*>(wrow + 16 * s);
-        const float bias = b1[c0 + r32];
+        for (int s = 0; s < 4; ++s) cw.w[s] = w1q[(ci * 4 + s) * 64];
+        cw.bias = b1[ci * MF_MC + r32];
+    };
+    auto load_w2 = [&](int ci, W2& cw) {
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) cw.w[ob][s] = w2q[((ci * 2 + ob) * 2 + s) * 64];
+    };
+
+    auto expand = [&](int ci, const W1& cw) {
+        char* dst = A1 + (ci & 1) * A1_BYTES;
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
             const int pb = wave + 8 * j;
             if (pb < NBLK) {   // wave-uniform
                 f32x16 acc;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                for (int i = 0; i < 16; ++i) acc[i] = cw.bias;   // the folded BN1 shift rides in the accumulator
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc = Mf<T>::mma(xf[j][s], wf[s], acc);
+                for (int s = 0; s < 4; ++s) acc = Mf<T>::mma(xf[j][s], cw.w[s], acc);
                 char* pl = dst + r32 * (A1P * 2) + (32 * pb + 4 * h) * 2;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float a = fminf(fmaxf(acc[4 * g + i] + bias, 0.f), 6.f);
-                        v[i] = ((valid[j] >> (4 * g + i)) & 1u) ? a : 0.f;
-                    }
-                    *reinterpret_cast<uint2*>(pl + 16 * g) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+                    for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_fmed3f(acc[4 * g + i], 0.f, 6.f);
+                    *reinterpret_cast<uint2*>(pl + 16 * g) =
+                        make_uint2(pack2<T>(v[0], v[1]) & mk[j][2 * g], pack2<T>(v[2], v[3]) & mk[j][2 * g + 1]);
                 }
             }
         }
@@ -281,10 +321,13 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
     auto depthwise = [&](int ci) {
         const int c0 = ci * MF_MC;
         const char* src = A1 + (ci & 1) * A1_BYTES;
-#pragma unroll 1
+        // K = 3: the 4 channels' tap rows (16 words each) are requested together; K = 5 / 7: one at a time (the scalar
+        // register file holds ~100 words; two K = 5 rows at once measured slower)
+        constexpr int CH_UNROLL = K == 3 ? 4 : 1;
+#pragma unroll CH_UNROLL
         for (int i = 0; i < MF_MC / 8; ++i) {
             const int cc = wave * (MF_MC / 8) + i;
-            const uint32_t* tp = taps + (long long)(c0 + cc) * G::TAPS;    // wave-uniform: scalar loads
+            const uint32_t* tp = taps + (long long)(c0 + cc) * G::TAPROW;    // wave-uniform: scalar loads
             const char* pl = src + cc * (A1P * 2) + (row16 * MF_WC + 4 * q4) * 2;
             float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -294,50 +337,51 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
                 const uint2 cq = *reinterpret_cast<const uint2*>(pl + ky * (MF_WC * 2) + 16);
                 const uint32_t d[6] = {a.x, a.y, bq.x, bq.y, cq.x, cq.y};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    constexpr int dummy = 0;
-                    (void)dummy;
-                    const int t = j + 4 - P;            // first window column of output j, relative to the lane's 12
-                    const int base = t >> 1, odd = t & 1;
+                for (int m = 0; m < NPAIR; ++m)          // pair index outside: consecutive v_dot2c feed different accumulators
 #pragma unroll
-                    for (int m = 0; m < NPAIR; ++m)
+                    for (int j = 0; j < 4; ++j) {
+                        const int t = j + 4 - P;        // first window column of output j, relative to the lane's 12
+                        const int base = t >> 1, odd = t & 1;
                         o[j] = Mf<T>::dot2(tp[ky * 2 * NPAIR + odd * NPAIR + m], d[base + m], o[j]);
-                }
+                    }
             }
-            const float bias = b2[c0 + cc];
+            const float bias = __uint_as_float(tp[G::TAPS]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = fminf(fmaxf(o[j] + bias, 0.f), 6.f);
+            for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_fmed3f(o[j] + bias, 0.f, 6.f);
             *reinterpret_cast<uint2*>(A2 + cc * (MF_A2P * 2) + (row16 * MF_T + 4 * q4) * 2) =
                 make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
         }
     };
 
-    auto project = [&](int ci) {
-        const int c0 = ci * MF_MC;
+    auto project = [&](const W2& cw) {
         s16x8 af[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) af[s] = mf_frag(A2, MF_A2P * 2, 32 * wave, s, lane);
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob) {
-            const T* wrow = w2f + (long long)(32 * ob + r32) * mid + c0 + 8 * h;
+        for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                oacc[ob] = Mf<T>::mma(af[s], *reinterpret_cast<const s16x8*>(wrow + 16 * s), oacc[ob]);
-        }
+            for (int s = 0; s < 2; ++s) oacc[ob] = Mf<T>::mma(af[s], cw.w[ob][s], oacc[ob]);
     };
 
     // ---- chunk pipeline: [E(i) || D(i-1)] barrier [P(i-1)] barrier
+    W1 cur, nxt;
+    W2 pw;
+    load_w1(0, cur);
+    nxt = cur;
     for (int i = 0; i <= nchunk; ++i) {
+        if (i + 1 < nchunk) load_w1(i + 1, nxt);
+        if (i > 0) load_w2(i - 1, pw);
         if (wave < 4) {
-            if (i < nchunk) expand(i);
+            if (i < nchunk) expand(i, cur);
             if (i > 0) depthwise(i - 1);
         } else {
             if (i > 0) depthwise(i - 1);
-            if (i < nchunk) expand(i);
+            if (i < nchunk) expand(i, cur);
         }
         __syncthreads();
-        if (i > 0) project(i - 1);
+        if (i > 0) project(pw);
         __syncthreads();
+        cur = nxt;
     }
 
     // ---- epilogue: + b3, stage fp32 [64][SP], then 16-byte row pieces (+ shortcut)
@@ -354,35 +398,46 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
     __syncthreads();
     T* on = out + (long long)n * 64 * plane;
     const bool w8 = (W & 7) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    constexpr int NPC = 64 * 16 * 2 / MF_THREADS;   // 16-byte row pieces per thread
+    if (w8 && h0 + MF_T <= H && w0 + MF_T <= W) {
+        // whole tile inside the image, aligned rows: straight-line code, the shortcut pieces requested together
+        uint4 xr[NPC];
 #pragma unroll
-    for (int it = 0; it < 64 * 16 * 2 / MF_THREADS; ++it) {
-        const int e = tid + it * MF_THREADS;
-        const int half = e & 1, rr = (e >> 1) & 15, o = e >> 5;
-        const int gh = h0 + rr, gw = w0 + 8 * half;
-        if (gh >= H || gw >= W) continue;
-        const float* sp = St + o * MF_SP + rr * MF_T + 8 * half;
-        const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
-        float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const long long off = (long long)o * plane + (long long)gh * W + gw;
-        if (w8 && gw + 8 <= W) {
-            if (residual) {
-                const uint4 xr = *reinterpret_cast<const uint4*>(xn + off);
-                const uint32_t xw[4] = {xr.x, xr.y, xr.z, xr.w};
+        for (int it = 0; it < NPC; ++it) {
+            const int e = tid + it * MF_THREADS;
+            const int half = e & 1, rr = (e >> 1) & 15, o = e >> 5;
+            xr[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (residual) xr[it] = *reinterpret_cast<const uint4*>(xn + (long long)o * plane + (long long)(h0 + rr) * W + w0 + 8 * half);
+        }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    T lo, hi;
-                    lo.v = (uint16_t)(xw[i] & 0xffffu);
-                    hi.v = (uint16_t)(xw[i] >> 16);
-                    v[2 * i] += to_float(lo);
-                    v[2 * i + 1] += to_float(hi);
-                }
+        for (int it = 0; it < NPC; ++it) {
+            const int e = tid + it * MF_THREADS;
+            const int half = e & 1, rr = (e >> 1) & 15, o = e >> 5;
+            const float* sp = St + o * MF_SP + rr * MF_T + 8 * half;
+            const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+            float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            const uint32_t xw[4] = {xr[it].x, xr[it].y, xr[it].z, xr[it].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                T lo, hi;
+                lo.v = (uint16_t)(xw[i] & 0xffffu);
+                hi.v = (uint16_t)(xw[i] >> 16);
+                v[2 * i] += to_float(lo);        // +0 when there is no shortcut (xr = 0 bits = +0.0 in both formats)
+                v[2 * i + 1] += to_float(hi);
             }
-            *reinterpret_cast<uint4*>(on + off) = make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]),
-                                                             pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
-        } else {
+            *reinterpret_cast<uint4*>(on + (long long)o * plane + (long long)(h0 + rr) * W + w0 + 8 * half) =
+                make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
+        }
+    } else {   // tiles cut by the image border, ragged widths: element-wise
+        for (int e = tid; e < 64 * 16 * 2; e += MF_THREADS) {
+            const int half = e & 1, rr = (e >> 1) & 15, o = e >> 5;
+            const int gh = h0 + rr, gw = w0 + 8 * half;
+            if (gh >= H || gw >= W) continue;
+            const float* sp = St + o * MF_SP + rr * MF_T + 8 * half;
+            const long long off = (long long)o * plane + (long long)gh * W + gw;
             for (int i = 0; i < 8 && gw + i < W; ++i) {
                 const float xv = residual ? to_float(xn[off + i]) : 0.f;
-                on[off + i] = from_float<T>(v[i] + xv);
+                on[off + i] = from_float<T>(sp[i] + xv);
             }
         }
     }
@@ -399,7 +454,7 @@ static MfWs mf_ws(int64_t mid, int K) {
     s.f = o;    o += mf_align((size_t)mid * K * K * sizeof(float));
     s.w1f = o;  o += mf_align((size_t)mid * 64 * 2);
     s.b1 = o;   o += mf_align((size_t)mid * sizeof(float));
-    s.taps = o; o += mf_align((size_t)mid * K * 2 * npair * sizeof(uint32_t));
+    s.taps = o; o += mf_align((size_t)mid * ((K * 2 * npair + 1 + 3) / 4 * 4) * sizeof(uint32_t));
     s.b2 = o;   o += mf_align((size_t)mid * sizeof(float));
     s.w2f = o;  o += mf_align((size_t)64 * mid * 2);
     s.b3 = o;   o += mf_align(64 * sizeof(float));

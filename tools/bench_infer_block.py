@@ -37,7 +37,8 @@ def main():
         for K in (7, 5, 3):
             layer.active_kernel_size, layer.active_expand_ratio = K, e
             mid = layer.active_middle_channel(64)
-            row = []
+            C = importlib.import_module(PKG + "._C")
+            row, ktime = [], {}
             for fused in (True, False):
                 ops.FUSED_INFER = fused
                 with torch.no_grad():
@@ -51,7 +52,23 @@ def main():
                     t1.record()
                     torch.cuda.synchronize()
                 row.append(1e3 * t0.elapsed_time(t1) / a.reps)
+                # device time of the kernels themselves (events around every launch, include/ofasr.h Diagnostics): the
+                # python-level number above is host-bound at these sizes
+                C.lib().ofasr_profile_enable(1)
+                with torch.no_grad():
+                    for _ in range(a.reps):
+                        block(x)
+                C.lib().ofasr_profile_enable(0)
+                prof = C.profile_read()
+                ktime[fused] = sum(v["total_us"] for v in prof.values()) / a.reps
+                if fused:
+                    main = [v for k, v in prof.items() if k.startswith("mb_fused_kernel")][0]
+                    kmain = main["total_us"] / main["launches"]
             ops.FUSED_INFER = True
+            tfk = 2.0 * px * 2 * 64 * mid / (kmain * 1e-6) / 1e12
+            print("   kernels only: fused block %.1f us (mb_fused_kernel %.1f us = %.0f GB/s, 1x1 %.0f TFLOP/s = %.1f %% of peak) | "
+                  "composite eval kernels %.1f us | x%.2f" % (ktime[True], kmain, 3.0 * px * 128 / (kmain * 1e-6) / 1e9, tfk,
+                                                            100 * tfk / 2500.0, ktime[False], ktime[False] / ktime[True]))
             us = row[0]
             gb = 3.0 * px * 64 * 2 / (us * 1e-6) / 1e9
             tf = 2.0 * px * 2 * 64 * mid / (us * 1e-6) / 1e12
