@@ -19,9 +19,10 @@
 //        positions outside the image forced to 0 (the depthwise conv pads the ACTIVATED tensor with zeros), 16-bit,
 //        written as channel planes (4 adjacent pixels per lane: the accumulator rows) -> A1[buf]
 //     D  depthwise k x k on the vector pipe from the planes: a lane owns 4 adjacent outputs of one row; two taps per
-//        v_dot2c_f32_{bf16,f16} (fp32 accumulation of exact 16-bit products): the pair tables E = (f0 f1)(f2 f3).. and
-//        O = (0 f0)(f1 f2).. make every pair sit on an aligned dword of the plane whatever the output's parity, taps are
-//        wave-uniform (scalar loads), + b2, ReLU6, 16-bit -> A2
+//        v_dot2c_f32_{bf16,f16} (fp32 accumulation of exact 16-bit products) against the pair table (f0 f1)(f2 f3)..;
+//        outputs whose window starts on an odd column read the row shifted by one (v_alignbit), so one table serves
+//        all; taps are wave-uniform scalar registers, the next channel's row requested a channel ahead; + b2, ReLU6,
+//        16-bit -> A2
 //     P  project on the matrix cores: out[32 px x 64] += a2^T[32 px x 32 ch] . W2f^T[32 x 64]  (accumulators resident)
 //     waves 4-7 run D before E so that the two waves of a SIMD are on different pipes (matrix || vector)
 //   epilogue  + b3 (+ x), staged through LDS so that the tile leaves as 16-byte row pieces.
@@ -59,7 +60,7 @@ template <int K> struct MfGeom {
     static constexpr int NB_WAVE = (NBLK + 7) / 8;          // pixel blocks per wave (3 / 2 / 2)
     static constexpr int A1P = NBLK * 32 + 4;               // plane pitch: = 4 (mod 8) -> 8-byte stores of 16 planes spread over banks
     static constexpr int NPAIR = (K + 1) / 2;               // tap pairs per kernel row and parity
-    static constexpr int TAPS = K * 2 * NPAIR;              // tap-pair dwords per channel
+    static constexpr int TAPS = K * NPAIR;                  // tap-pair dwords per channel: (f0 f1)(f2 f3)..(f_{K-1} 0) per kernel row
     static constexpr int TAPROW = (TAPS + 1 + 3) / 4 * 4;   // + the BN2 bias, padded: one scalar-load row per channel
 };
 
@@ -126,25 +127,21 @@ __global__ void __launch_bounds__(256) mb_fold_kernel(MfFold p, T* __restrict__ 
         const int o = 32 * ob + (l & 31), c = 32 * ci + 16 * s2 + 8 * (l >> 5) + j;
         w2f[e] = from_float<T>(p.w2[(long long)o * p.ldw2 + c] * scale(2, o));
     }
-    const int TAPROW = (K * 2 * NPAIR + 1 + 3) / 4 * 4;
+    const int TAPROW = (K * NPAIR + 1 + 3) / 4 * 4;
     for (int c = tid; c < mid; c += nth) {
         b1[c] = p.beta[0][c] - p.mean[0][c] * scale(0, c);
         b2[c] = p.beta[1][c] - p.mean[1][c] * scale(1, c);
-        taps[(long long)c * TAPROW + K * 2 * NPAIR] = __float_as_uint(b2[c]);   // the row's last word: BN2 bias
+        taps[(long long)c * TAPROW + K * NPAIR] = __float_as_uint(b2[c]);   // the row's last word: BN2 bias
     }
     for (int o = tid; o < 64; o += nth) b3[o] = p.beta[2][o] - p.mean[2][o] * scale(2, o);
-    // tap pairs: per (channel, kernel row) E pairs (f0 f1)(f2 f3)..(f_{K-1} 0), then O pairs (0 f0)(f1 f2)..(f_{K-2} f_{K-1});
-    // the low half multiplies the lower window column
-    for (int e = tid; e < mid * K * 2 * NPAIR; e += nth) {
-        const int c = e / (K * 2 * NPAIR), r = e - c * (K * 2 * NPAIR);
-        const int ky = r / (2 * NPAIR), m = r - ky * 2 * NPAIR;
-        const bool odd = m >= NPAIR;
-        const int i = odd ? m - NPAIR : m;
-        const int t0 = odd ? 2 * i - 1 : 2 * i, t1 = t0 + 1;
+    // tap pairs per (channel, kernel row): (f0 f1)(f2 f3)..(f_{K-1} 0); the low half multiplies the lower column
+    for (int e = tid; e < mid * K * NPAIR; e += nth) {
+        const int c = e / (K * NPAIR), r = e - c * (K * NPAIR);
+        const int ky = r / NPAIR, m = r - ky * NPAIR;
         const float s = scale(1, c);
         const float* fr = p.f + ((long long)c * K + ky) * K;
-        const float lo = (t0 >= 0 && t0 < K) ? fr[t0] * s : 0.f;
-        const float hi = (t1 >= 0 && t1 < K) ? fr[t1] * s : 0.f;
+        const float lo = fr[2 * m] * s;
+        const float hi = (2 * m + 1 < K) ? fr[2 * m + 1] * s : 0.f;
         taps[(long long)c * TAPROW + r] = (uint32_t)from_float<T>(lo).v | ((uint32_t)from_float<T>(hi).v << 16);
     }
 }
@@ -321,35 +318,70 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
     auto depthwise = [&](int ci) {
         const int c0 = ci * MF_MC;
         const char* src = A1 + (ci & 1) * A1_BYTES;
-        // K = 3: the 4 channels' tap rows (16 words each) are requested together; K = 5 / 7: one at a time (the scalar
-        // register file holds ~100 words; two K = 5 rows at once measured slower)
-        constexpr int CH_UNROLL = K == 3 ? 4 : 1;
-#pragma unroll CH_UNROLL
-        for (int i = 0; i < MF_MC / 8; ++i) {
-            const int cc = wave * (MF_MC / 8) + i;
-            const uint32_t* tp = taps + (long long)(c0 + cc) * G::TAPROW;    // wave-uniform: scalar loads
+        constexpr int NCH = MF_MC / 8;          // channels per wave and chunk
+        constexpr int TW = G::TAPS + 1;
+        // The taps are wave-uniform and live in scalar registers; the row of channel i+1 is requested before channel i
+        // is computed (two sets fit: 29 words at K = 7), so the scalar-load latency -- the phase runs at two waves per
+        // SIMD and was bound by exactly this wait -- is covered by the previous channel's products.
+        uint32_t tc[TW], tn[TW];
+        {
+            const uint32_t* tp = taps + (long long)(c0 + wave * NCH) * G::TAPROW;
+#pragma unroll
+            for (int q = 0; q < TW; ++q) tc[q] = tp[q];
+        }
+        // window rows of the first PF kernel rows of a channel are requested one channel ahead as well (before the
+        // previous channel's a2 store: both live in the one LDS array, so the compiler will not hoist them itself)
+        constexpr int PF = K == 7 ? 3 : K;
+        uint2 rw[K][3], rn[PF][3];
+        auto load_rows = [&](int cc, int k0, int k1, uint2 (*dst)[3]) {
             const char* pl = src + cc * (A1P * 2) + (row16 * MF_WC + 4 * q4) * 2;
+#pragma unroll
+            for (int ky = k0; ky < k1; ++ky) {
+                dst[ky - k0][0] = *reinterpret_cast<const uint2*>(pl + ky * (MF_WC * 2));
+                dst[ky - k0][1] = *reinterpret_cast<const uint2*>(pl + ky * (MF_WC * 2) + 8);
+                dst[ky - k0][2] = *reinterpret_cast<const uint2*>(pl + ky * (MF_WC * 2) + 16);
+            }
+        };
+        load_rows(wave * NCH, 0, PF, rn);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int cc = wave * NCH + i;
+#pragma unroll
+            for (int ky = 0; ky < PF; ++ky)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) rw[ky][q] = rn[ky][q];
+            if constexpr (PF < K) load_rows(cc, PF, K, rw + PF);
+            if (i + 1 < NCH) {
+                const uint32_t* tp = taps + (long long)(c0 + cc + 1) * G::TAPROW;
+#pragma unroll
+                for (int q = 0; q < TW; ++q) tn[q] = tp[q];
+                load_rows(cc + 1, 0, PF, rn);
+            }
             float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
-                const uint2 a = *reinterpret_cast<const uint2*>(pl + ky * (MF_WC * 2));
-                const uint2 bq = *reinterpret_cast<const uint2*>(pl + ky * (MF_WC * 2) + 8);
-                const uint2 cq = *reinterpret_cast<const uint2*>(pl + ky * (MF_WC * 2) + 16);
-                const uint32_t d[6] = {a.x, a.y, bq.x, bq.y, cq.x, cq.y};
+                const uint32_t d[6] = {rw[ky][0].x, rw[ky][0].y, rw[ky][1].x, rw[ky][1].y, rw[ky][2].x, rw[ky][2].y};   // window columns 4 q4 .. 4 q4 + 11
+                // the same columns shifted by one: ds[m] = columns (2m+1, 2m+2), for the outputs whose window starts on an
+                // odd column -- every output then uses the ONE pair table (f0 f1)(f2 f3)..
+                uint32_t ds[5];
+#pragma unroll
+                for (int m = 0; m < 5; ++m) ds[m] = __builtin_amdgcn_alignbit(d[m + 1], d[m], 16);
 #pragma unroll
                 for (int m = 0; m < NPAIR; ++m)          // pair index outside: consecutive v_dot2c feed different accumulators
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int t = j + 4 - P;        // first window column of output j, relative to the lane's 12
-                        const int base = t >> 1, odd = t & 1;
-                        o[j] = Mf<T>::dot2(tp[ky * 2 * NPAIR + odd * NPAIR + m], d[base + m], o[j]);
+                        const int base = t >> 1;
+                        o[j] = Mf<T>::dot2(tc[ky * NPAIR + m], (t & 1) ? ds[base + m] : d[base + m], o[j]);
                     }
             }
-            const float bias = __uint_as_float(tp[G::TAPS]);
+            const float bias = __uint_as_float(tc[G::TAPS]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_fmed3f(o[j] + bias, 0.f, 6.f);
             *reinterpret_cast<uint2*>(A2 + cc * (MF_A2P * 2) + (row16 * MF_T + 4 * q4) * 2) =
                 make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
+#pragma unroll
+            for (int q = 0; q < TW; ++q) tc[q] = tn[q];
         }
     };
 
@@ -454,7 +486,7 @@ static MfWs mf_ws(int64_t mid, int K) {
     s.f = o;    o += mf_align((size_t)mid * K * K * sizeof(float));
     s.w1f = o;  o += mf_align((size_t)mid * 64 * 2);
     s.b1 = o;   o += mf_align((size_t)mid * sizeof(float));
-    s.taps = o; o += mf_align((size_t)mid * ((K * 2 * npair + 1 + 3) / 4 * 4) * sizeof(uint32_t));
+    s.taps = o; o += mf_align((size_t)mid * ((K * npair + 1 + 3) / 4 * 4) * sizeof(uint32_t));
     s.b2 = o;   o += mf_align((size_t)mid * sizeof(float));
     s.w2f = o;  o += mf_align((size_t)64 * mid * 2);
     s.b3 = o;   o += mf_align(64 * sizeof(float));
