@@ -172,7 +172,7 @@ int ofasr_bn_act_bwd(const void* dy, const void* x, const void* residual, void* 
  *          y = pre-BN conv outputs, a = activated tensors; `out` is the block output.  Kept for backward.
  * stat_buf (fp32) per BN i in {expand, depthwise, project}: mean | invstd | scale | shift (4*C_i, C = mid, mid,
  *          Cout), then the active depthwise filter f [mid*K*K].
- * bwd: tmp_buf (activation dtype) 2*N*mid*HW + N*Cout*HW elements of scratch; every gradient tensor is
+ * bwd: tmp_buf (activation dtype) 3*N*mid*HW + N*Cout*HW elements of scratch; every gradient tensor is
  *          FULLY written (dense max-size parameter gradients, zeros outside the active slice).
  * ------------------------------------------------------------------------------------------- */
 typedef struct {

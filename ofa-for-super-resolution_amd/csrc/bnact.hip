@@ -446,6 +446,37 @@ __global__ void __launch_bounds__(BN_THREADS) bn_bwd_apply_kernel(const T* __res
     }
 }
 
+// dgamma / dbeta and the BwdXf coefficients of channel c from the reduction partials (fixed order; the Pred loads are
+// requested together)
+__global__ void __launch_bounds__(64) bn_bwd_coef_kernel(const double* __restrict__ partial, int Pred, int C, double M,
+                                                         int training, const float* __restrict__ scale,
+                                                         const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, float* __restrict__ ka,
+                                                         float* __restrict__ kbi) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, sx = 0.0;
+    for (int q0 = 0; q0 < Pred; q0 += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = q0 + j < Pred ? q0 + j : Pred - 1;
+            a[j] = partial[((long long)q * C + c) * 2];
+            b[j] = partial[((long long)q * C + c) * 2 + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s += q0 + j < Pred ? a[j] : 0.0;
+            sx += q0 + j < Pred ? b[j] : 0.0;
+        }
+    }
+    if (dgamma) dgamma[c] = (float)sx;
+    if (dbeta) dbeta[c] = (float)s;
+    const double sc = (double)scale[c];
+    ka[c] = training ? (float)(sc * (s / M)) : 0.f;
+    kbi[c] = training ? (float)(sc * (double)invstd[c] * (sx / M)) : 0.f;
+}
+
 static int bn_parts(int64_t N, int64_t C) {
     // enough blocks to fill the chip (256 CUs x ~8 blocks), at most one image per part
     int64_t want = cdiv(2048, C > 0 ? C : 1);
@@ -753,6 +784,41 @@ OFASR_EXPORT int ofasr_bn_act_bwd(const void* dy, const void* x, const void* res
 #undef OFASR_BN_BOTH
     return check_launch(name);
 }
+
+namespace ofasr {
+int bn_bwd_reduce_coef(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
+                       const float* invstd, float* dgamma, float* dbeta, float* ka, float* kbi, int64_t N, int64_t C,
+                       int64_t HW, int act, int training, int dtype, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+    const char* name = "bn_bwd_reduce_coef";
+    int rc = check_bn(name, N, C, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(dy && x && scale && shift && mean && invstd && ka && kbi, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    const int P = bn_parts(N, C);
+    const size_t need = (size_t)P * C * 2 * sizeof(double);
+    OFASR_REQUIRE(workspace && workspace_bytes >= need, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", name,
+                  workspace_bytes, need);
+    double* partial = (double*)workspace;
+    dim3 grid((unsigned)C, (unsigned)P);
+    hipStream_t st = as_stream(stream);
+    const bool v = vec_ok(HW, dtype, dy, x, nullptr, nullptr);
+    const void* residual = nullptr;
+    prof_note((dtype == OFASR_F32 ? 4.0 : 2.0) * (double)N * (double)C * (double)HW * 2.0, 0.0);
+#define OFASR_BNR2(VEC, ACT)                                                                                           \
+    OFASR_LAUNCH((bn_bwd_reduce_kernel<T, VEC, ACT, false>), grid, dim3(BN_THREADS), 0, st, (const T*)dy, (const T*)x, \
+                 (const T*)residual, scale, shift, mean, invstd, partial, (int)N, (int)C, (int)HW, P)
+    OFASR_BN_DISPATCH_T(dtype, {
+        if (v) { if (act == 1) OFASR_BNR2(true, 1); else OFASR_BNR2(true, 0); }
+        else { if (act == 1) OFASR_BNR2(false, 1); else OFASR_BNR2(false, 0); }
+    });
+#undef OFASR_BNR2
+    rc = check_launch(name);
+    if (rc) return rc;
+    OFASR_LAUNCH(bn_bwd_coef_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, (const double*)partial, P, (int)C,
+                 (double)N * (double)HW, training, scale, invstd, dgamma, dbeta, ka, kbi);
+    return check_launch(name);
+}
+}  // namespace ofasr
 
 OFASR_EXPORT size_t ofasr_bn_act_bwd_workspace(int64_t N, int64_t C) {
     if (N <= 0 || C <= 0) return 0;

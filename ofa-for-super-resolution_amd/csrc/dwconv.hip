@@ -328,10 +328,11 @@ constexpr int DWM_PITCH = 144;
 // accesses across the point (and drains the LDS queue), which is all a wave-private buffer needs
 __device__ __forceinline__ void dwm_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <typename T, int K, bool FLIP, bool XF, bool STAT>
+template <typename T, int K, bool FLIP, bool XF, bool STAT, bool BX = false>
 __global__ void __launch_bounds__(64 * DW_WAVES) dw_mfma_kernel(const T* __restrict__ x, const float* __restrict__ f,
                                                                 T* __restrict__ y, int N, int C, int H, int W,
-                                                                int nslabs, InputXf xf, StatOut so, BnFold fold) {
+                                                                int nslabs, InputXf xf, StatOut so, BnFold fold,
+                                                                BwdXf bx = BwdXf{}) {
     constexpr int PAD = K / 2;
     constexpr int LROWS = 64 + 2 * PAD;
     // plane image rows of DWM_PITCH bytes: 8 data chunks of 16 B + ONE zero chunk (index 8) that serves as the left pad
@@ -425,6 +426,15 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_mfma_kernel(const T* __restr
         }
     }
 
+    float bmu = 0.f, bsc = 1.f, bxb = 0.f, bka = 0.f, bkbi = 0.f;   // BN(+ReLU6) backward of the input plane (BwdXf)
+    if constexpr (BX) {
+        bmu = bx.mean[c];
+        bsc = bx.scale[c];
+        bxb = fmaf(bmu, bsc, bx.shift[c]);
+        bka = bx.ka[c];
+        bkbi = bx.kbi[c];
+    }
+
     int abase[2][3];   // byte offset of this lane's fragment chunk for (column block, chunk pair), row r
 #pragma unroll
     for (int wb = 0; wb < 2; ++wb)
@@ -438,6 +448,7 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_mfma_kernel(const T* __restr
     const int nchunks = H * cpr;            // <= 512: at most 8 chunks per lane
     char* O = outs[wave];
     uint4 nxt[8];
+    uint4 nxt2[BX ? 8 : 1];   // BwdXf: the pre-BN plane y beside the gradient plane
     auto load_plane = [&](int pl) {
         const long long plane = (long long)(n0 + pl) * C + c;
         const uint4* src = reinterpret_cast<const uint4*>(x + plane * (long long)H * W);
@@ -446,6 +457,15 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_mfma_kernel(const T* __restr
             const int idx = lane + 64 * it;
             nxt[it] = make_uint4(0, 0, 0, 0);
             if (idx < nchunks) nxt[it] = src[idx];
+        }
+        if constexpr (BX) {
+            const uint4* src2 = reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(bx.y) + plane * (long long)H * W);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = lane + 64 * it;
+                nxt2[it] = make_uint4(0, 0, 0, 0);
+                if (idx < nchunks) nxt2[it] = src2[idx];
+            }
         }
     };
     load_plane(0);
@@ -469,6 +489,26 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_mfma_kernel(const T* __restr
                         wv[i] = pack2<T>(a, b);
                     }
                     v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                }
+                if constexpr (BX) {   // dy = scale*dz - ka - (y - mean)*kbi, dz = da inside the ReLU6 window of BN(y)
+                    uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+                    const uint32_t yv[4] = {nxt2[it].x, nxt2[it].y, nxt2[it].z, nxt2[it].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        T lo, hi, ylo, yhi;
+                        lo.v = (uint16_t)(wv[i] & 0xffffu);
+                        hi.v = (uint16_t)(wv[i] >> 16);
+                        ylo.v = (uint16_t)(yv[i] & 0xffffu);
+                        yhi.v = (uint16_t)(yv[i] >> 16);
+                        const float t0 = to_float(ylo) - bmu, t1 = to_float(yhi) - bmu;
+                        const float p0 = fmaf(t0, bsc, bxb), p1 = fmaf(t1, bsc, bxb);
+                        const float z0 = (p0 > 0.f && p0 < 6.f) ? to_float(lo) : 0.f;
+                        const float z1 = (p1 > 0.f && p1 < 6.f) ? to_float(hi) : 0.f;
+                        wv[i] = pack2<T>(fmaf(-t0, bkbi, fmaf(bsc, z0, -bka)), fmaf(-t1, bkbi, fmaf(bsc, z1, -bka)));
+                    }
+                    v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                    if (bx.dy_out)   // wave-uniform: the plane's dy, once, for the weight-gradient kernel
+                        reinterpret_cast<uint4*>(reinterpret_cast<T*>(bx.dy_out) + plane * (long long)H * W)[idx] = v;
                 }
                 const int row = idx / cpr, chunk = idx - row * cpr, lr = row + PAD;
                 *reinterpret_cast<uint4*>(L + lr * DWM_PITCH + (chunk << 4)) = v;
@@ -551,11 +591,12 @@ struct VecGeom {
 };
 
 // wave = (plane, slab); group g of the wave owns rows [slab*gpw*R + g*R, +R) of that plane
-template <typename T, int K, bool FLIP, bool XF = false, bool STAT = false>
+template <typename T, int K, bool FLIP, bool XF = false, bool STAT = false, bool BX = false>
 __global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restrict__ x, const float* __restrict__ f,
                                                                T* __restrict__ y, int C, int H, int W, VecGeom vg,
                                                                long long nwaves, InputXf xf = InputXf{},
-                                                               StatOut so = StatOut{nullptr, 0}, BnFold fold = BnFold{}) {
+                                                               StatOut so = StatOut{nullptr, 0}, BnFold fold = BnFold{},
+                                                               BwdXf bx = BwdXf{}) {
     constexpr int PAD = K / 2;
     constexpr int PXL = VecPx<T, K>::N;
     typedef PxIO<T, PXL> IO;
@@ -571,6 +612,14 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restri
     float taps[K * K];
 #pragma unroll
     for (int e = 0; e < K * K; ++e) taps[e] = f[(long long)c * K * K + (FLIP ? (K * K - 1 - e) : e)];
+    float bmu = 0.f, bsc = 1.f, bxb = 0.f, bka = 0.f, bkbi = 0.f;   // BN(+ReLU6) backward of the input plane (BwdXf)
+    if constexpr (BX) {
+        bmu = bx.mean[c];
+        bsc = bx.scale[c];
+        bxb = fmaf(bmu, bsc, bx.shift[c]);
+        bka = bx.ka[c];
+        bkbi = bx.kbi[c];
+    }
     float xsc = 1.f, xmu = 0.f, xb = 0.f;            // fused BN + ReLU6 of the input plane (wave-uniform)
     if constexpr (XF) {
         if (fold.cp) {
@@ -651,9 +700,18 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restri
         const int hin = hstart + t;
         return (live && t < niter && hin >= 0 && hin < H) ? xp[(long long)hin * Wq] : IO::zero();
     };
+    const raw_t* yp2 = BX ? reinterpret_cast<const raw_t*>(reinterpret_cast<const T*>(bx.y) + plane * (long long)H * W) + gl : nullptr;
+    auto load_row2 = [&](int t) -> raw_t {   // BwdXf: the pre-BN plane beside the gradient plane
+        const int hin = hstart + t;
+        return (BX && live && t < niter && hin >= 0 && hin < H) ? yp2[(long long)hin * Wq] : IO::zero();
+    };
     raw_t raw[K];   // software ring: K row loads in flight per lane
+    raw_t raw2[BX ? K : 1];
 #pragma unroll
-    for (int u = 0; u < K; ++u) raw[u] = load_row(u);
+    for (int u = 0; u < K; ++u) {
+        raw[u] = load_row(u);
+        if constexpr (BX) raw2[u] = load_row2(u);
+    }
     for (int base = 0; base < niter_max; base += K) {
 #pragma unroll
         for (int u = 0; u < K; ++u) {
@@ -665,6 +723,21 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restri
                 const bool rv = live && t < niter && hin >= 0 && hin < H;
 #pragma unroll
                 for (int p = 0; p < PXL; ++p) v[p] = rv ? fminf(fmaxf(fmaf(v[p] - xmu, xsc, xb), 0.f), 6.f) : 0.f;
+            }
+            if constexpr (BX) {   // dy = scale*dz - ka - (y - mean)*kbi; rows outside the image are zero padding
+                float yv[PXL];
+                IO::unpack(raw2[u], yv);
+                const bool rv = live && t < niter && hin >= 0 && hin < H;
+#pragma unroll
+                for (int p = 0; p < PXL; ++p) {
+                    const float tt = yv[p] - bmu, pre = fmaf(tt, bsc, bxb);
+                    const float dz = (pre > 0.f && pre < 6.f) ? v[p] : 0.f;
+                    v[p] = rv ? fmaf(-tt, bkbi, fmaf(bsc, dz, -bka)) : 0.f;
+                }
+                raw2[u] = load_row2(t + K);
+                // rows [h0, h1) belong to this lane group (halo rows are some other group's): each dy row is stored once
+                if (bx.dy_out && rv && hin >= h0 && hin < h1)
+                    (reinterpret_cast<raw_t*>(reinterpret_cast<T*>(bx.dy_out) + plane * (long long)H * W) + gl)[(long long)hin * Wq] = IO::pack(v);
             }
             raw[u] = load_row(t + K);
             build_window<PXL, PAD>(v, win, lane, has_left, has_right);
@@ -841,10 +914,10 @@ static int wgrad_parts(int64_t N, int64_t C) {
     return (int)want;
 }
 
-template <typename T, bool FLIP, bool XF = false, bool STAT = false>
+template <typename T, bool FLIP, bool XF = false, bool STAT = false, bool BX = false>
 static int launch_conv(const char* name, const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H,
                        int64_t W, int K, hipStream_t st, InputXf xf = InputXf{}, StatOut so = StatOut{nullptr, 0},
-                       BnFold fold = BnFold{}) {
+                       BnFold fold = BnFold{}, BwdXf bx = BwdXf{}) {
     prof_note(2.0 * sizeof(T) * (double)N * (double)C * (double)H * (double)W + 4.0 * (double)C * K * K,
               2.0 * K * K * (double)N * (double)C * (double)H * (double)W);
     if constexpr (sizeof(T) == 2) {
@@ -857,13 +930,13 @@ static int launch_conv(const char* name, const void* x, const float* f, void* y,
             }
             const long long units = (long long)C * cdiv(N, DWM_NPW);
             if (K == 5)
-                OFASR_LAUNCH((dw_mfma_kernel<T, 5, FLIP, XF, STAT>), dim3((unsigned)cdiv(units, DW_WAVES)),
+                OFASR_LAUNCH((dw_mfma_kernel<T, 5, FLIP, XF, STAT, BX>), dim3((unsigned)cdiv(units, DW_WAVES)),
                                    dim3(64 * DW_WAVES), 0, st, (const T*)x, f, (T*)y, (int)N, (int)C, (int)H, (int)W, nslabs,
-                                   xf, so, fold);
+                                   xf, so, fold, bx);
             else
-                OFASR_LAUNCH((dw_mfma_kernel<T, 7, FLIP, XF, STAT>), dim3((unsigned)cdiv(units, DW_WAVES)),
+                OFASR_LAUNCH((dw_mfma_kernel<T, 7, FLIP, XF, STAT, BX>), dim3((unsigned)cdiv(units, DW_WAVES)),
                                    dim3(64 * DW_WAVES), 0, st, (const T*)x, f, (T*)y, (int)N, (int)C, (int)H, (int)W, nslabs,
-                                   xf, so, fold);
+                                   xf, so, fold, bx);
             return check_launch(name);
         }
     }
@@ -876,9 +949,9 @@ static int launch_conv(const char* name, const void* x, const float* f, void* y,
             set_error("%s: statistics slab count %d != %lld", name, so.P, (long long)(N * vg.nslabs));             \
             return OFASR_ERR_INVALID_ARG;                                                                          \
         }                                                                                                          \
-        OFASR_LAUNCH((dw_vec_kernel<T, KK, FLIP, XF, STAT>), dim3((unsigned)cdiv(nwaves, DW_WAVES)),         \
+        OFASR_LAUNCH((dw_vec_kernel<T, KK, FLIP, XF, STAT, BX>), dim3((unsigned)cdiv(nwaves, DW_WAVES)),     \
                            dim3(64 * DW_WAVES), 0, st, (const T*)x, f, (T*)y, (int)C, (int)H, (int)W, vg, nwaves,  \
-                           xf, so, fold);                                                                          \
+                           xf, so, fold, bx);                                                                      \
         return check_launch(name);                                                                                 \
     }
         switch (K) {
@@ -889,7 +962,7 @@ static int launch_conv(const char* name, const void* x, const float* f, void* y,
         }
 #undef OFASR_DWV
     }
-    if constexpr (XF) {
+    if constexpr (XF || BX) {
         set_error("%s: fused input transform needs the vector kernel", name);
         return OFASR_ERR_UNSUPPORTED;
     }
@@ -1042,6 +1115,26 @@ int dwconv_wgrad_xf(const void* dy, const void* x, float* df, int64_t N, int64_t
     hipStream_t st = as_stream(stream);
     if (dtype == OFASR_F16) return launch_wgrad<f16_t, true>(name, dy, x, df, N, C, H, W, K, (float*)workspace, st, xf);
     return launch_wgrad<bf16_t, true>(name, dy, x, df, N, C, H, W, K, (float*)workspace, st, xf);
+}
+
+// input gradient of the depthwise conv with the gradient operand read through the BN(+ReLU6) backward (BwdXf):
+// dx = dwconv_dgrad(dy(da, y), f); 16-bit, vector / matrix-core shapes only (dwconv_xf_supported)
+int dwconv_dgrad_bx(const void* da, const float* f, void* dx, int64_t N, int64_t C, int64_t H, int64_t W, int K,
+                    int dtype, BwdXf bx, void* stream) {
+    const char* name = "dwconv_dgrad_bx";
+    int rc = check_conv_args(name, da, f, dx, N, C, H, W, K, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(bx.y && bx.mean && bx.scale && bx.shift && bx.ka && bx.kbi, OFASR_ERR_INVALID_ARG, "%s: null transform", name);
+    OFASR_REQUIRE(dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_UNSUPPORTED, "%s: 16-bit only", name);
+    OFASR_REQUIRE(((reinterpret_cast<uintptr_t>(bx.y) | reinterpret_cast<uintptr_t>(bx.dy_out)) & 15) == 0,
+                  OFASR_ERR_UNSUPPORTED, "%s: unaligned y / dy_out", name);
+    if (N * C * H * W == 0) return OFASR_OK;
+    hipStream_t st = as_stream(stream);
+    if (dtype == OFASR_F16)
+        return launch_conv<f16_t, true, false, false, true>(name, da, f, dx, N, C, H, W, K, st, InputXf{}, StatOut{nullptr, 0},
+                                                            BnFold{}, bx);
+    return launch_conv<bf16_t, true, false, false, true>(name, da, f, dx, N, C, H, W, K, st, InputXf{}, StatOut{nullptr, 0},
+                                                         BnFold{}, bx);
 }
 
 }  // namespace ofasr

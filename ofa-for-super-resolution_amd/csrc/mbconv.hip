@@ -29,6 +29,7 @@ struct MbSizes {
     size_t stat_a;        // bytes of the first statistics-partials region inside it (BN1 / BN3); BN2's follows
     size_t side;          // side-stream region shared by whichever weight-gradient kernel is running
     size_t df_bytes;      // depthwise filter gradient (lives from dw wgrad to the kernel-transform backward)
+    size_t coef_off;      // BN1 / BN2 backward coefficients (ka | kbi each, mid floats): read by both streams
     size_t total;
 };
 
@@ -61,7 +62,8 @@ static MbSizes mb_sizes(const ofasr_mbconv_desc* d) {
     }
     s.side = s.ws_dw > s.ws_pw ? s.ws_dw : s.ws_pw;
     s.df_bytes = align_up((size_t)(d->mid * d->K * d->K) * sizeof(float), 256);
-    s.total = s.scratch + s.side + s.df_bytes + s.ws_kt + 256;
+    s.coef_off = s.scratch + s.side + s.df_bytes + s.ws_kt + 256;
+    s.total = s.coef_off + align_up((size_t)(4 * d->mid) * sizeof(float), 256);
     return s;
 }
 
@@ -392,7 +394,7 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     // unjoined side work of earlier calls that still reads the scratch this call is about to overwrite
     SideStream& ss = side_stream();
     const char* t_lo = (const char*)tmp_buf;
-    const char* t_hi = t_lo + (2 * s.mid_elems + (size_t)d->N * d->Cout * HW) * s.es;
+    const char* t_hi = t_lo + (3 * s.mid_elems + (size_t)d->N * d->Cout * HW) * s.es;
     const char* w_lo = (const char*)workspace;
     const char* w_hi = w_lo + workspace_bytes;
     bool defer = false;
@@ -480,8 +482,51 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     if (rc) return rc;
     rc = ofasr_pwconv_dgrad(t3, d->w2, d->ldw2, tA, d->N, d->mid, d->Cout, HW, d->dtype, stream);
     if (rc) return rc;
-    // BN2 + ReLU6 (in place: da2 -> dy2)
     StatView s2 = stat_view(sb, 1, d->mid, d->Cout);
+    StatView s1 = stat_view(sb, 0, d->mid, d->Cout);
+    // BN1 / BN2 backward without the apply pass (OFASR_MBCONV_BN_BWD_FOLD=0 restores it): the reduction pass leaves
+    // (ka, kbi) per channel; the consumer of dy2 / dy1 on this chain -- the depthwise / expand input gradient -- forms the
+    // gradient from (da, y) as it reads them (BwdXf) and stores it once for the weight-gradient kernel of the side
+    // stream.  Per BN the chain loses a pass ("read da, read y, write dy"), a launch and one tensor of traffic.  (Reading
+    // (da, y) in the weight-gradient kernels too, instead of the stored dy, was measured slower: 2122 against 2261 img/s --
+    // those kernels bound the side stream, which then bounds the step.)
+    static const bool bn_fold = [] { const char* e = getenv("OFASR_MBCONV_BN_BWD_FOLD"); return !(e && e[0] == '0'); }();
+    float* coef = reinterpret_cast<float*>((char*)workspace + s.coef_off);
+    void* tC = t + (2 * s.mid_elems + (size_t)d->N * d->Cout * HW) * s.es;   // mid: dy2, left there by the depthwise dgrad
+    const BwdXf bx2{y2, s2.mean, s2.scale, s2.shift, coef, coef + d->mid, tC};
+    const BwdXf bx1{y1, s1.mean, s1.scale, s1.shift, coef + 2 * d->mid, coef + 3 * d->mid, tA};   // dy1 over the dead da2
+    const bool bxp = fused && bn_fold && dwconv_xf_supported(tA, tB, d->H, d->W, d->K, d->dtype) &&
+                     (reinterpret_cast<uintptr_t>(tC) & 15) == 0 &&
+                     pwconv_dgrad_bx_supported(tB, y1, dx, d->residual ? dout : nullptr, d->w1, d->ldw1, d->Cin, d->mid, HW,
+                                               d->dtype);
+    if (bxp) {
+        rc = bn_bwd_reduce_coef(tA, y2, s2.scale, s2.shift, s2.mean, s2.invstd, g->dgamma[1], g->dbeta[1], coef, coef + d->mid,
+                                d->N, d->mid, HW, 1, d->bn_training[1], d->dtype, workspace, s.scratch, stream);
+        if (rc) return rc;
+        rc = dwconv_dgrad_bx(tA, f, tB, d->N, d->mid, d->H, d->W, d->K, d->dtype, bx2, stream);   // also leaves dy2 in tC
+        if (rc) return rc;
+        rc = fork(1);   // dy2 (tC) is final
+        if (rc) return rc;
+        rc = dwconv_wgrad_xf(tC, y1, dfp, d->N, d->mid, d->H, d->W, d->K, d->dtype, xf_of(stat_buf, 0, d->mid, d->Cout),
+                             side_ws, s.side, sst);
+        if (rc) return rc;
+        rc = ofasr_ktransform_bwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, dfp, g->dwdw_max, g->dmats,
+                                  d->mid, kt_ws, s.ws_kt + 256, sst);
+        if (rc) return rc;
+        rc = bn_bwd_reduce_coef(tB, y1, s1.scale, s1.shift, s1.mean, s1.invstd, g->dgamma[0], g->dbeta[0], coef + 2 * d->mid,
+                                coef + 3 * d->mid, d->N, d->mid, HW, 1, d->bn_training[0], d->dtype, workspace, s.scratch,
+                                stream);
+        if (rc) return rc;
+        // expand input gradient (+ the shortcut's dout); leaves dy1 in tA (da2 there is dead: its one reader ran above)
+        rc = pwconv_dgrad_add_bx(tB, d->w1, d->ldw1, dx, d->residual ? dout : nullptr, d->N, d->Cin, d->mid, HW, d->dtype, bx1,
+                                 stream);
+        if (rc) return rc;
+        rc = fork(2);   // dy1 (tA) is final
+        if (rc) return rc;
+        rc = ofasr_pwconv_wgrad(tA, x, g->dw1, d->ldw1, d->N, d->Cin, d->mid, HW, d->dtype, side_ws, s.side, sst);
+        if (rc) return rc;
+    } else {
+    // BN2 + ReLU6 (in place: da2 -> dy2)
     rc = ofasr_bn_act_bwd(tA, y2, nullptr, tA, nullptr, s2.scale, s2.shift, s2.mean, s2.invstd, g->dgamma[1],
                           g->dbeta[1], d->N, d->mid, HW, 1, d->bn_training[1], d->dtype, workspace, s.scratch, stream);
     if (rc) return rc;
@@ -501,7 +546,6 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     rc = ofasr_dwconv_dgrad(tA, f, tB, d->N, d->mid, d->H, d->W, d->K, d->dtype, stream);
     if (rc) return rc;
     // BN1 + ReLU6 (in place: da1 -> dy1)
-    StatView s1 = stat_view(sb, 0, d->mid, d->Cout);
     rc = ofasr_bn_act_bwd(tB, y1, nullptr, tB, nullptr, s1.scale, s1.shift, s1.mean, s1.invstd, g->dgamma[0],
                           g->dbeta[0], d->N, d->mid, HW, 1, d->bn_training[0], d->dtype, workspace, s.scratch, stream);
     if (rc) return rc;
@@ -516,6 +560,7 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     else
         rc = ofasr_pwconv_dgrad(tB, d->w1, d->ldw1, dx, d->N, d->Cin, d->mid, HW, d->dtype, stream);
     if (rc) return rc;
+    }
     if (par) {
         std::lock_guard<std::mutex> lk(ss.mu);
         if (defer) {   // remember what the side kernels still use; ofasr_mbconv_join orders them before the caller

@@ -127,6 +127,30 @@ struct InputXf {
     const float* mean;
 };
 
+// BatchNorm(+ReLU6) BACKWARD applied to an operand as a kernel reads it: the gradient dy of the pre-BN tensor y is
+//     t = y - mean;  pre = t*scale + beta;  dz = (0 < pre < 6) ? da : 0;  dy = scale*dz - ka - t*kbi
+// (ka = scale * mean(dz), kbi = scale * invstd * mean(dz * xhat); both 0 for eval-mode BN) formed from the incoming
+// gradient da and y on the fly, so the "apply" pass of the BN backward -- read da, read y, write dy -- never runs and dy
+// is a pass of its own no more.  The per-channel sums behind ka / kbi come from bn_bwd_reduce_coef.  The kernel that
+// consumes dy on the input-gradient chain also stores it once (dy_out, may be null) for the weight-gradient kernel on the
+// side stream: compared with the separate pass the chain moves one tensor less (no second read of da) and loses a
+// launch, and the side stream reads what it read before.  y == nullptr: plain read.
+struct BwdXf {
+    const void* y;        // the pre-BN tensor, same shape and element type as the gradient operand
+    const float* mean;
+    const float* scale;   // gamma * invstd
+    const float* shift;   // beta - mean * scale
+    const float* ka;
+    const float* kbi;
+    void* dy_out;         // where the consumer leaves dy (same shape / element type), or nullptr
+};
+// reduction pass of the BN(+ReLU6) backward + a C-thread kernel that turns the partials into dgamma, dbeta and the
+// (ka, kbi) of BwdXf.  workspace: ofasr_bn_act_bwd_workspace(N, C) bytes.
+int bn_bwd_reduce_coef(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
+                       const float* invstd, float* dgamma, float* dbeta, float* ka, float* kbi, int64_t N, int64_t C,
+                       int64_t HW, int act, int training, int dtype, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 // A consumer kernel can fold the producer's epilogue partials itself (no finalize launch between the two): every
 // block derives scale / mean / beta of the channels it reads from partial[c * P + 0..P) in fp64 in a fixed order, and
 // one designated block also writes mean | invstd | scale | shift (kept for the backward) and the running statistics.
@@ -172,6 +196,8 @@ int dwconv_fwd_xf(const void* x, const float* f, void* y, int64_t N, int64_t C, 
                   InputXf xf, void* stream, StatOut so = StatOut{nullptr, 0}, BnFold fold = BnFold{});
 int dwconv_wgrad_xf(const void* dy, const void* x, float* df, int64_t N, int64_t C, int64_t H, int64_t W, int K,
                     int dtype, InputXf xf, void* workspace, size_t workspace_bytes, void* stream);
+int dwconv_dgrad_bx(const void* da, const float* f, void* dx, int64_t N, int64_t C, int64_t H, int64_t W, int K,
+                    int dtype, BwdXf bx, void* stream);
 // ofasr_bn_finalize that also bumps up to three num_batches_tracked counters (thread 0)
 int bn_finalize_bump(const void* workspace, int64_t n_partials, int64_t C, double count, const float* gamma,
                      const float* beta, float* running_mean, float* running_var, double momentum, double eps,
@@ -180,6 +206,10 @@ int bn_finalize_bump(const void* workspace, int64_t n_partials, int64_t C, doubl
 // dx = W^T dy + addend (the identity shortcut's gradient joins in the epilogue of the expand conv's input gradient)
 int pwconv_dgrad_add(const void* dy, const float* w, int64_t ldw, void* dx, const void* addend, int64_t N, int64_t Cin,
                      int64_t Cout, int64_t HW, int dtype, void* stream);
+bool pwconv_dgrad_bx_supported(const void* da, const void* y, const void* dx, const void* addend, const float* w,
+                               int64_t ldw, int64_t Cin, int64_t Cout, int64_t HW, int dtype);
+int pwconv_dgrad_add_bx(const void* da, const float* w, int64_t ldw, void* dx, const void* addend, int64_t N, int64_t Cin,
+                        int64_t Cout, int64_t HW, int dtype, BwdXf bx, void* stream);
 bool pwconv_xf_supported(const void* x, const void* y, int64_t HW, int dtype);
 int pwconv_fwd_xf(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t HW,
                   int dtype, InputXf xf, void* stream, StatOut so = StatOut{nullptr, 0});

@@ -202,6 +202,27 @@ __device__ __forceinline__ uint4 xf_apply8_core(uint4 v, float sc, float mu, flo
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// BN(+ReLU6) backward of 8 packed gradient values `g` of one channel given the 8 pre-BN values `yv` (BwdXf)
+template <typename T>
+__device__ __forceinline__ uint4 bx_apply8(uint4 g, uint4 yv, float mu, float sc, float xb, float ka, float kbi) {
+    uint32_t w[4] = {g.x, g.y, g.z, g.w};
+    const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        T lo, hi, ylo, yhi;
+        lo.v = (uint16_t)(w[i] & 0xffffu);
+        hi.v = (uint16_t)(w[i] >> 16);
+        ylo.v = (uint16_t)(yw[i] & 0xffffu);
+        yhi.v = (uint16_t)(yw[i] >> 16);
+        const float t0 = to_float(ylo) - mu, t1 = to_float(yhi) - mu;
+        const float p0 = fmaf(t0, sc, xb), p1 = fmaf(t1, sc, xb);
+        const float z0 = (p0 > 0.f && p0 < 6.f) ? to_float(lo) : 0.f;
+        const float z1 = (p1 > 0.f && p1 < 6.f) ? to_float(hi) : 0.f;
+        w[i] = pack2<T>(fmaf(-t0, kbi, fmaf(sc, z0, -ka)), fmaf(-t1, kbi, fmaf(sc, z1, -ka)));
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 template <typename T, int PX, bool ALIGNED, bool XF = false>
 __device__ __forceinline__ void stage_x_tile(char* Xs, const T* __restrict__ xn, int K, int HW, int k0, int p0,
                                              InputXf xf = InputXf{}) {
@@ -777,15 +798,28 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_kernel(const T* __restric
 // barriers and the MFMAs of a round hide behind the next chunk's HBM round trip instead of adding to it (measured
 // timeline of the plain loop: ~10 us of loads + 3.4 us of rounds + W latency, nothing overlapped).
 constexpr int FOLD_KMAX = 512;   // input channels a block can fold statistics for (3 LDS tables)
-template <typename T, bool XF, bool FAST = false>
+// BX: the X operand is a gradient read through the BN(+ReLU6) backward (BwdXf; needs FAST and K <= FOLD_KMAX)
+template <typename T, bool XF, bool FAST = false, bool BX = false>
 __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y,
                                                                    int HW, int tiles_per_img, int kchunks, InputXf xf,
                                                                    const T* __restrict__ addend, StatOut so,
-                                                                   BnFold fold = BnFold{}) {
+                                                                   BnFold fold = BnFold{}, BwdXf bx = BwdXf{}) {
     __shared__ __attribute__((aligned(16))) char Ws[64 * WROW16];
     __shared__ __attribute__((aligned(16))) char Xs[64 * XROW16];
     __shared__ float fsc[XF ? FOLD_KMAX : 1], fmu[XF ? FOLD_KMAX : 1], fb[XF ? FOLD_KMAX : 1];
+    __shared__ float bxt[BX ? 5 * FOLD_KMAX : 1];   // per input channel: mean | scale | beta' | ka | kbi
     const int tid = threadIdx.x;
+    if constexpr (BX) {
+        for (int ch = tid; ch < wv.K; ch += PW_THREADS) {
+            const float mu = bx.mean[ch], sc = bx.scale[ch];
+            bxt[ch] = mu;
+            bxt[FOLD_KMAX + ch] = sc;
+            bxt[2 * FOLD_KMAX + ch] = fmaf(mu, sc, bx.shift[ch]);
+            bxt[3 * FOLD_KMAX + ch] = bx.ka[ch];
+            bxt[4 * FOLD_KMAX + ch] = bx.kbi[ch];
+        }
+        __syncthreads();
+    }
     const bool folded = XF && fold.cp != nullptr;
     if constexpr (XF) {
         if (folded) {   // the input BN's finalize, per block: channel ch from its P partials, fixed order, fp64
@@ -843,10 +877,12 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __re
     const int n = tile / tiles_per_img;
     const int p0 = (tile - n * tiles_per_img) * PW_TILE;
     const T* xn = x + (long long)n * wv.K * HW;
+    const T* yn2 = BX ? reinterpret_cast<const T*>(bx.y) + (long long)n * wv.K * HW : nullptr;
     T* yn = y + ((long long)n * wv.M + m_base) * HW;
     const bool rowmajor = wv.sk == 1;
 
     uint4 xr[4];
+    uint4 yr[BX ? 4 : 1];
     float4 wr[4];
     uint32_t okbits = 0;   // FAST: bit it = weight chunk it is inside the slice, bit 4+it = X vector it is
     auto load_chunk = [&](int kc) {
@@ -880,6 +916,7 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __re
                 const int k = k0 + (q >> 4), px = p0 + 8 * (q & 15);
                 const bool ok = k < wv.K && px < HW;
                 xr[it] = *reinterpret_cast<const uint4*>(xn + (ok ? (long long)k * HW + px : 0));
+                if constexpr (BX) yr[it] = *reinterpret_cast<const uint4*>(yn2 + (ok ? (long long)k * HW + px : 0));
                 okbits |= (ok ? 16u : 0u) << it;
             }
             return;
@@ -953,6 +990,16 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __re
                 if (64 * kc + k < wv.K && p0 + 8 * m < HW) {
                     const int ch = 64 * kc + k;
                     v = folded ? xf_apply8_core<T>(v, fsc[ch], fmu[ch], fb[ch]) : xf_apply8<T>(v, xf, ch);
+                }
+            }
+            if constexpr (BX) {   // chunks outside the slice were zeroed above and stay zero (ka of a dead chunk is not applied)
+                if ((okbits >> (4 + it)) & 1u) {
+                    const int ch = 64 * kc + k;
+                    v = bx_apply8<T>(v, yr[it], bxt[ch], bxt[FOLD_KMAX + ch], bxt[2 * FOLD_KMAX + ch], bxt[3 * FOLD_KMAX + ch],
+                                     bxt[4 * FOLD_KMAX + ch]);
+                    // the tile's dy, once (the blocks of the first output-row slab), for the weight-gradient kernel
+                    if (bx.dy_out && blockIdx.y == 0)
+                        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(bx.dy_out) + ((long long)n * wv.K + ch) * HW + p0 + 8 * m) = v;
                 }
             }
             // pixel 8m+i -> position 64*(m>>3) + 32*(i&1) + 4*(m&7) + (i>>1)   (stage_x_tile, PX = 2)
@@ -1192,7 +1239,7 @@ struct WdPlan {
     int quads_per_img, total_quads, nsplit, MR, NS;
 };
 
-// XF: 0 none, 1 the R operand, 2 the S operand is read through the fused BN + ReLU6
+// XF: 0 none, 1 the R operand, 2 the S operand is read through the fused BN + ReLU6 (InputXf)
 template <typename T, int XF = 0>
 __global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restrict__ R, const T* __restrict__ S,
                                                               float* __restrict__ part, int MR, int NS, int HW,
@@ -1211,52 +1258,67 @@ __global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restric
     const int q0 = (int)((long long)split * wp.total_quads / wp.nsplit);
     const int q1 = (int)((long long)(split + 1) * wp.total_quads / wp.nsplit);
     const bool cs = col < NS;
+    const int colc = cs ? col : NS - 1;                          // clamped: every request goes to a valid address
     bool rs[WD_RB];
+    int rowc[WD_RB];
 #pragma unroll
-    for (int rb = 0; rb < WD_RB; ++rb) rs[rb] = row0 + 32 * rb + c < MR;
-    // fused BN + ReLU6 of the x operand: this lane's rows / column are fixed, so are its channel constants
+    for (int rb = 0; rb < WD_RB; ++rb) {
+        rs[rb] = row0 + 32 * rb + c < MR;
+        rowc[rb] = rs[rb] ? row0 + 32 * rb + c : MR - 1;
+    }
+    // fused transforms: this lane's rows / column are fixed, so are its channel constants
     float xsc[WD_RB], xmu[WD_RB], xb[WD_RB];
     float csc = 1.f, cmu = 0.f, cbb = 0.f;
     if constexpr (XF == 1) {
 #pragma unroll
         for (int rb = 0; rb < WD_RB; ++rb) {
-            const int ch = min(row0 + 32 * rb + c, MR - 1);
-            xsc[rb] = xf.scale[ch];
-            xmu[rb] = xf.mean[ch];
-            xb[rb] = fmaf(xmu[rb], xsc[rb], xf.shift[ch]);
+            xsc[rb] = xf.scale[rowc[rb]];
+            xmu[rb] = xf.mean[rowc[rb]];
+            xb[rb] = fmaf(xmu[rb], xsc[rb], xf.shift[rowc[rb]]);
         }
     }
     if constexpr (XF == 2) {
-        const int ch = min(col, NS - 1);
-        csc = xf.scale[ch];
-        cmu = xf.mean[ch];
-        cbb = fmaf(cmu, csc, xf.shift[ch]);
+        csc = xf.scale[colc];
+        cmu = xf.mean[colc];
+        cbb = fmaf(cmu, csc, xf.shift[colc]);
     }
     for (int q = q0; q < q1; ++q) {
         const int n = q / wp.quads_per_img;
         const int px = (q - n * wp.quads_per_img) * 64 + 32 * h;   // this lane's first pixel
+        // Straight-line requests from clamped addresses, dead lanes / chunks zeroed afterwards: a load under a lane-
+        // dependent branch ends its basic block with s_waitcnt vmcnt(0), which had made the 16 requests of a quad as many
+        // serial round trips
         uint4 a[WD_RB][4], b[4];
-        const T* sp = S + ((long long)n * NS + col) * HW + px;
+        bool okp[4];
+        int pxc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            b[j] = make_uint4(0, 0, 0, 0);
-            if (cs && px + 8 * j < HW) {
-                b[j] = *reinterpret_cast<const uint4*>(sp + 8 * j);
-                if constexpr (XF == 2) b[j] = xf_apply8_core<T>(b[j], csc, cmu, cbb);
-            }
+            okp[j] = px + 8 * j < HW;
+            pxc[j] = okp[j] ? px + 8 * j : 0;
         }
+        const T* sp = S + ((long long)n * NS + colc) * HW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const uint4*>(sp + pxc[j]);
 #pragma unroll
         for (int rb = 0; rb < WD_RB; ++rb) {
-            const T* rp = R + ((long long)n * MR + row0 + 32 * rb + c) * HW + px;
+            const long long roff = ((long long)n * MR + rowc[rb]) * HW;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                a[rb][j] = make_uint4(0, 0, 0, 0);
-                if (rs[rb] && px + 8 * j < HW) {
-                    a[rb][j] = *reinterpret_cast<const uint4*>(rp + 8 * j);
-                    if constexpr (XF == 1) a[rb][j] = xf_apply8_core<T>(a[rb][j], xsc[rb], xmu[rb], xb[rb]);
-                }
+                a[rb][j] = *reinterpret_cast<const uint4*>(R + roff + pxc[j]);
             }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (XF == 2) b[j] = xf_apply8_core<T>(b[j], csc, cmu, cbb);
+            if (!(cs && okp[j])) b[j] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rb = 0; rb < WD_RB; ++rb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (XF == 1) a[rb][j] = xf_apply8_core<T>(a[rb][j], xsc[rb], xmu[rb], xb[rb]);
+                if (!(rs[rb] && okp[j])) a[rb][j] = make_uint4(0, 0, 0, 0);
+            }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1481,6 +1543,49 @@ int pwconv_dgrad_add(const void* dy, const float* w, int64_t ldw, void* dx, cons
     if (N * HW == 0) return OFASR_OK;
     WView wv{w, 1, ldw, (int)Cin, (int)Cout};
     return gemm_entry(name, dy, wv, dx, N, HW, dtype, stream, addend);
+}
+
+// expand input gradient with the gradient operand dy1 read through the BN(+ReLU6) backward:  dx = W^T dy1(da, y) + addend.
+// Only the pipelined fan-in kernel implements it: 16-bit, aligned, 64 < Cout <= FOLD_KMAX, vector-loadable weight slice.
+bool pwconv_dgrad_bx_supported(const void* da, const void* y, const void* dx, const void* addend, const float* w,
+                               int64_t ldw, int64_t Cin, int64_t Cout, int64_t HW, int dtype) {
+    if (dtype != OFASR_F16 && dtype != OFASR_BF16) return false;
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(da) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dx) |
+                           reinterpret_cast<uintptr_t>(addend) | reinterpret_cast<uintptr_t>(w);   // dy_out: checked by the caller
+    static const bool fast_ok = [] { const char* e = getenv("OFASR_PW_FANIN_FAST"); return !(e && e[0] == '0'); }();
+    return fast_ok && (bits & 15) == 0 && HW % 8 == 0 && ldw % 4 == 0 && Cin % 4 == 0 && Cout % 4 == 0 && Cout > 64 &&
+           Cout <= FOLD_KMAX;
+}
+
+template <typename T>
+static int launch_dgrad_bx(const char* name, const void* da, WView wv, void* dx, const void* addend, int64_t N, int64_t HW,
+                           BwdXf bx, hipStream_t st) {
+    const int tiles_per_img = (int)cdiv(HW, PW_TILE);
+    const int64_t total64 = N * tiles_per_img;
+    OFASR_REQUIRE(total64 <= INT32_MAX, OFASR_ERR_UNSUPPORTED, "%s: too many pixel tiles", name);
+    {
+        const double px = (double)N * (double)HW, es = (double)sizeof(T);
+        prof_note(es * px * (2.0 * wv.K + wv.M + (addend ? wv.M : 0)) + 4.0 * wv.K * wv.M, 2.0 * px * wv.K * wv.M);
+    }
+    dim3 grid((unsigned)total64, (unsigned)cdiv(wv.M, 64));
+    OFASR_LAUNCH((pw_fanin_pipe_kernel<T, false, true, true>), grid, dim3(PW_THREADS), 0, st, (const T*)da, wv, (T*)dx,
+                 (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), InputXf{}, (const T*)addend, StatOut{nullptr, 0}, BnFold{}, bx);
+    return check_launch(name);
+}
+
+int pwconv_dgrad_add_bx(const void* da, const float* w, int64_t ldw, void* dx, const void* addend, int64_t N, int64_t Cin,
+                        int64_t Cout, int64_t HW, int dtype, BwdXf bx, void* stream) {
+    const char* name = "pwconv_dgrad_add_bx";
+    int rc = check_pw_args(name, da, w, dx, ldw, N, Cin, Cout, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(bx.y && bx.mean && bx.scale && bx.shift && bx.ka && bx.kbi, OFASR_ERR_INVALID_ARG, "%s: null transform", name);
+    OFASR_REQUIRE(pwconv_dgrad_bx_supported(da, bx.y, dx, addend, w, ldw, Cin, Cout, HW, dtype), OFASR_ERR_UNSUPPORTED,
+                  "%s: needs the pipelined fan-in kernel (aligned 16-bit tensors, 64 < Cout <= %d)", name, FOLD_KMAX);
+    if (N * HW == 0) return OFASR_OK;
+    WView wv{w, 1, ldw, (int)Cin, (int)Cout};   // dgrad: M = Cin rows of W^T, K = Cout
+    hipStream_t st = as_stream(stream);
+    if (dtype == OFASR_F16) return launch_dgrad_bx<f16_t>(name, da, wv, dx, addend, N, HW, bx, st);
+    return launch_dgrad_bx<bf16_t>(name, da, wv, dx, addend, N, HW, bx, st);
 }
 
 bool pwconv_xf_supported(const void* x, const void* y, int64_t HW, int dtype) {

@@ -622,7 +622,7 @@ class FusedMBConvFn(Function):
         HW = H * W
         dout = dout.contiguous()
         dx = torch.empty_like(x)
-        tmp = _bwd_scratch(N * HW * (2 * d.mid + d.Cout), x.dtype, x.device)
+        tmp = _bwd_scratch(N * HW * (3 * d.mid + d.Cout), x.dtype, x.device)
         # the nine zero-initialised buffers first and adjacent: the library then clears them with one fill
         sizes = [w1.numel(), w2.numel(), wdw.numel()] + [g1.numel()] * 2 + [g2.numel()] * 2 + [g3.numel()] * 2 \
             + [m.numel() for m in mats]
