@@ -255,7 +255,8 @@ int ofasr_mbconv_infer(const ofasr_mbconv_desc* d, const void* x, void* out, voi
  * workspace: fwd / dgrad: the per-call 16-bit weight image, ofasr_conv2d_workspace(Cin, Cout, K, dgrad) bytes;
  *            wgrad: the split-K partial slabs, ofasr_conv2d_wgrad_workspace(N, Cin, Cout, H, W, K) bytes.
  * ofasr_conv2d_wgrad writes every element of dw (no accumulation into it); the summation order is fixed.
- * Returns OFASR_ERR_UNSUPPORTED for fp32 / other K / unaligned shapes (the caller then uses the vendor path).
+ * Returns OFASR_ERR_UNSUPPORTED for fp32 (use ofasr_conv2d_f32_*), other K and W % 8 != 0 (the host mirror zero-pads
+ * ragged widths on the right, which is the convolution's own padding, and drops the extra output columns).
  * ------------------------------------------------------------------------------------------- */
 size_t ofasr_conv2d_workspace(int64_t Cin, int64_t Cout, int K, int dgrad);
 int ofasr_conv2d_fwd(const void* x, const float* w, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
@@ -265,6 +266,21 @@ int ofasr_conv2d_dgrad(const void* dy, const float* w, void* dx, int64_t N, int6
 size_t ofasr_conv2d_wgrad_workspace(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K);
 int ofasr_conv2d_wgrad(const void* dy, const void* x, float* dw, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
                        int64_t W, int K, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The same dense KxK convolution with fp32 activations (the reference's own arithmetic), on the fp32-input matrix
+ * instruction (csrc/conv2d_f32.hip): exact fp32 fma chains, any H / W, no alignment requirement.  x, y, dy, dx fp32
+ * NCHW; w / dw [Cout,Cin,K,K] fp32.  Workspaces: the per-call weight image (fwd / dgrad) and the split-K partial slabs
+ * (wgrad) from the matching queries; the wgrad summation order is fixed.
+ * ------------------------------------------------------------------------------------------- */
+size_t ofasr_conv2d_f32_workspace(int64_t Cin, int64_t Cout, int K, int dgrad);
+int ofasr_conv2d_f32_fwd(const void* x, const float* w, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
+                         int K, void* workspace, size_t workspace_bytes, void* stream);
+int ofasr_conv2d_f32_dgrad(const void* dy, const float* w, void* dx, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
+                           int64_t W, int K, void* workspace, size_t workspace_bytes, void* stream);
+size_t ofasr_conv2d_f32_wgrad_workspace(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K);
+int ofasr_conv2d_f32_wgrad(const void* dy, const void* x, float* dw, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
+                           int64_t W, int K, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PIL-exact 8-bit bicubic resize  -- replaces the host-side img.resize(size, Image.BICUBIC) that makes the

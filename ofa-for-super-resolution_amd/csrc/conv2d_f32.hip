@@ -1,0 +1,286 @@
+// conv2d_f32.hip -- the static ConvLayers' dense KxK convolution (K in {3,5}, stride 1, zero padding K/2) with fp32
+// activations, on the fp32-input matrix instruction v_mfma_f32_32x32x2_f32: forward, input gradient, weight gradient.
+//
+// Reference: nn.Conv2d in ConvLayer (ofa/layers.py:131-151; ofa_mbs4.py:65,105,120,123).  fp32 is the reference's own
+// arithmetic: this path serves the fp32 parity nets, the `fp32` leg of bench.py and fp32
+// evaluation (eval_ofa_net_sr.py) -- any H, W, no alignment requirement -- so that no layer of the SR nets leaves the
+// library.  The MFMA is an exact fp32 fma chain (one rounding per product, k-ordered), at the fp32 vector rate
+// (157 TFLOP/s peak = 1/16 of the bf16 matrix rate): the 16-bit kernels of conv2d.hip remain the fast path.
+//
+//   Y[n, m, h, w] = sum_{ty,tx} sum_k Wv(m, k, ty, tx) * X[n, k, h+ty-P, w+tx-P]
+//   forward: (m, k) = (co, ci), Wv = w[m][k][ty][tx];   input gradient: (m, k) = (ci, co), Wv = w[k][m][K-1-ty][K-1-tx]
+//
+// forward / dgrad kernel: block = 4 waves = 4 output rows x 32 columns x 64 output channels; wave w owns row w:
+// D[row = channel][col = pixel].  Per 16-channel input chunk the (4+K-1) x (32+K-1) window sits in LDS ([ci][row][col],
+// fp32) and, per kernel row ty, the weight slab [tx][16 k][64 m] (copied with 16-byte loads from an image laid out in
+// that order by conv_f32_prep_kernel): an A operand is one ds_read_b32 of 32 consecutive channels, a B operand one
+// ds_read_b32 of 32 consecutive pixels (both conflict-free), K*8*2 MFMAs per wave and (chunk, ty).
+// weight gradient: rows = co, columns = ci, reduction over pixels (2 per MFMA); a block of K waves owns a 32 x 32
+// (co, ci) tile and a range of 4 x 32 pixel tiles, wave ty keeps its K accumulators (tx) in registers over the whole
+// range; per-range partial slabs are summed in a fixed order (deterministic, no atomics).
+#include "ofasr_common.h"
+
+namespace ofasr {
+
+typedef __attribute__((ext_vector_type(16))) float cf_f32x16;
+
+constexpr int CF_TH = 4, CF_TW = 32, CF_KC = 16, CF_MB = 64;
+
+// weight image [kc][ty][tx][kk = 16][m = Mpad] fp32 (zeros beyond the slice)
+__global__ void __launch_bounds__(256) conv_f32_prep_kernel(const float* __restrict__ w, float* __restrict__ wimg, int Cin,
+                                                            int KS, int dgrad, int M, int Kdim, int Mpad, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int m = (int)(idx % Mpad);
+    long long t = idx / Mpad;
+    const int kk = (int)(t % CF_KC);
+    t /= CF_KC;
+    const int tx = (int)(t % KS);
+    t /= KS;
+    const int ty = (int)(t % KS);
+    const int kc = (int)(t / KS);
+    const int k = kc * CF_KC + kk;
+    float v = 0.f;
+    if (m < M && k < Kdim) {
+        const int taps = KS * KS, tap = ty * KS + tx;
+        v = dgrad ? w[((long long)k * Cin + m) * taps + (taps - 1 - tap)] : w[((long long)m * Cin + k) * taps + tap];
+    }
+    wimg[idx] = v;
+}
+
+template <int KS>
+__global__ void __launch_bounds__(256) conv_f32_kernel(const float* __restrict__ x, const float* __restrict__ wimg,
+                                                       float* __restrict__ y, int Kdim, int M, int Mpad, int H, int W,
+                                                       int tiles_x, int nkc) {
+    constexpr int P = KS / 2;
+    constexpr int RH = CF_TH + KS - 1, RW = CF_TW + KS - 1;
+    constexpr int XPL = RH * RW + 1;                        // plane pitch (odd: the two k-lanes of a fragment differ by a bank)
+    __shared__ float Xs[CF_KC * XPL];
+    __shared__ __attribute__((aligned(16))) float Ws[KS * CF_KC * CF_MB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, kk = lane >> 5;
+    const int tile = blockIdx.x, n = blockIdx.y, slab = blockIdx.z;
+    const int h0 = (tile / tiles_x) * CF_TH, w0 = (tile % tiles_x) * CF_TW;
+    const long long plane = (long long)H * W;
+    const float* xn = x + (long long)n * Kdim * plane;
+    cf_f32x16 acc[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
+
+    for (int kc = 0; kc < nkc; ++kc) {
+        __syncthreads();   // the previous chunk's readers are done with Xs / Ws
+        for (int e = tid; e < CF_KC * RH * RW; e += 256) {
+            const int ci = e / (RH * RW), r = (e - ci * (RH * RW)) / RW, col = e - ci * (RH * RW) - r * RW;
+            const int k = kc * CF_KC + ci, gh = h0 - P + r, gw = w0 - P + col;
+            float v = 0.f;
+            if (k < Kdim && gh >= 0 && gh < H && gw >= 0 && gw < W) v = xn[(long long)k * plane + (long long)gh * W + gw];
+            Xs[ci * XPL + r * RW + col] = v;
+        }
+        for (int ty = 0; ty < KS; ++ty) {
+            if (ty) __syncthreads();   // the previous kernel row's readers are done with Ws
+            {
+                const float4* src = reinterpret_cast<const float4*>(wimg + ((long long)(kc * KS + ty) * KS) * CF_KC * Mpad);
+                for (int q = tid; q < KS * CF_KC * (CF_MB / 4); q += 256) {
+                    const int m4 = q % (CF_MB / 4), rest = q / (CF_MB / 4);   // rest = tx*16 + kk
+                    reinterpret_cast<float4*>(Ws)[q] = src[(long long)rest * (Mpad / 4) + slab * (CF_MB / 4) + m4];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tx = 0; tx < KS; ++tx) {
+                const float* wt = Ws + tx * (CF_KC * CF_MB) + kk * CF_MB + c;
+                const float* xt = Xs + kk * XPL + (wave + ty) * RW + c + tx;
+#pragma unroll
+                for (int s = 0; s < CF_KC / 2; ++s) {
+                    const float b = xt[2 * s * XPL];
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[2 * s * CF_MB], b, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[2 * s * CF_MB + 32], b, acc[1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int oy = h0 + wave, ox = w0 + c;
+    if (oy < H && ox < W) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = slab * CF_MB + 32 * rb + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+                if (m < M) y[(((long long)n * M + m) * H + oy) * W + ox] = acc[rb][reg];
+            }
+    }
+}
+
+// ---- weight gradient: partial[split][co][ci][ty][tx] over the block's pixel tiles
+template <int KS>
+__global__ void __launch_bounds__(64 * KS) conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 float* __restrict__ part, int Cin, int Cout, int H, int W,
+                                                                 int tiles_x, int tiles_y, int ntiles, int nsplit) {
+    constexpr int P = KS / 2, THREADS = 64 * KS;
+    constexpr int RH = CF_TH + KS - 1, RW = CF_TW + KS - 1;
+    constexpr int GPL = CF_TH * CF_TW + 1;                  // dY plane pitch: bank = (co + pixel) % 32 -> conflict-free A reads
+    constexpr int XPL = RH * RW + 1;
+    __shared__ float Gs[32 * GPL];
+    __shared__ float Xs[32 * XPL];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's kernel row
+    const int c = lane & 31, kk = lane >> 5;
+    const int split = blockIdx.x, co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
+    const long long plane = (long long)H * W;
+    cf_f32x16 acc[KS];
+#pragma unroll
+    for (int tx = 0; tx < KS; ++tx)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tx][i] = 0.f;
+    const int t0 = (int)((long long)split * ntiles / nsplit), t1 = (int)((long long)(split + 1) * ntiles / nsplit);
+    for (int t = t0; t < t1; ++t) {
+        const int n = t / (tiles_x * tiles_y), rem = t - n * (tiles_x * tiles_y);
+        const int h0 = (rem / tiles_x) * CF_TH, w0 = (rem % tiles_x) * CF_TW;
+        __syncthreads();
+        for (int e = tid; e < 32 * CF_TH * CF_TW; e += THREADS) {
+            const int co = e / (CF_TH * CF_TW), p = e - co * (CF_TH * CF_TW);
+            const int gh = h0 + p / CF_TW, gw = w0 + p % CF_TW;
+            float v = 0.f;
+            if (co0 + co < Cout && gh < H && gw < W) v = dy[((long long)n * Cout + co0 + co) * plane + (long long)gh * W + gw];
+            Gs[co * GPL + p] = v;
+        }
+        for (int e = tid; e < 32 * RH * RW; e += THREADS) {
+            const int ci = e / (RH * RW), r = (e - ci * (RH * RW)) / RW, col = e - ci * (RH * RW) - r * RW;
+            const int gh = h0 - P + r, gw = w0 - P + col;
+            float v = 0.f;
+            if (ci0 + ci < Cin && gh >= 0 && gh < H && gw >= 0 && gw < W)
+                v = x[((long long)n * Cin + ci0 + ci) * plane + (long long)gh * W + gw];
+            Xs[ci * XPL + r * RW + col] = v;
+        }
+        __syncthreads();
+        // pixel pair s = (row r, columns 2q, 2q+1); lane (c, kk): A = dY[co = c][pixel 2s + kk], B = X[ci = c][same pixel + tap]
+#pragma unroll 2
+        for (int s = 0; s < CF_TH * CF_TW / 2; ++s) {
+            const int p = 2 * s + kk, r = p / CF_TW, col = p % CF_TW;
+            const float a = Gs[c * GPL + p];
+            const float* xb = Xs + c * XPL + (r + ty) * RW + col;
+#pragma unroll
+            for (int tx = 0; tx < KS; ++tx) acc[tx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[tx], acc[tx], 0, 0, 0);
+        }
+    }
+    // D[row = co][col = ci]
+    float* dst = part + (long long)split * Cout * Cin * KS * KS;
+    const int ci = ci0 + c;
+    if (ci < Cin) {
+#pragma unroll
+        for (int tx = 0; tx < KS; ++tx)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = co0 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+                if (co < Cout) dst[(((long long)co * Cin + ci) * KS + ty) * KS + tx] = acc[tx][reg];
+            }
+    }
+}
+
+__global__ void __launch_bounds__(256) conv_f32_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                    long long total, int nsplit) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += part[(long long)z * total + idx];
+    dw[idx] = s;
+}
+
+static int cf_mpad(int64_t M) { return (int)(cdiv(M, CF_MB) * CF_MB); }
+static int cf_nsplit(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W) {
+    const int64_t ntiles = N * cdiv(H, CF_TH) * cdiv(W, CF_TW);
+    const int64_t groups = cdiv(Cout, 32) * cdiv(Cin, 32);
+    int64_t want = 1024 / (groups > 0 ? groups : 1);   // ~4 blocks per CU
+    if (want > ntiles) want = ntiles;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+}  // namespace ofasr
+
+using namespace ofasr;
+
+OFASR_EXPORT size_t ofasr_conv2d_f32_workspace(int64_t Cin, int64_t Cout, int K, int dgrad) {
+    if (Cin <= 0 || Cout <= 0 || !(K == 3 || K == 5)) return 0;
+    const int64_t M = dgrad ? Cin : Cout, Kd = dgrad ? Cout : Cin;
+    return (size_t)cdiv(Kd, CF_KC) * K * K * CF_KC * cf_mpad(M) * sizeof(float);
+}
+
+static int conv2d_f32_entry(const char* name, const void* x, const float* w, void* y, int64_t N, int64_t Cin, int64_t Cout,
+                            int64_t H, int64_t W, int K, int dgrad, void* ws, size_t ws_bytes, void* stream) {
+    OFASR_REQUIRE(x && w && y, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, OFASR_ERR_INVALID_ARG, "%s: bad shape", name);
+    OFASR_REQUIRE(K == 3 || K == 5, OFASR_ERR_UNSUPPORTED, "%s: K=%d not in {3,5}", name, K);
+    OFASR_REQUIRE(N <= 65535 && H * W <= (1LL << 31), OFASR_ERR_UNSUPPORTED, "%s: too large", name);
+    const size_t need = ofasr_conv2d_f32_workspace(Cin, Cout, K, dgrad);
+    OFASR_REQUIRE(ws && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 15) == 0, OFASR_ERR_WORKSPACE,
+                  "%s: workspace %zu B < required %zu B (or not 16-byte aligned)", name, ws_bytes, need);
+    const int M = (int)(dgrad ? Cin : Cout), Kdim = (int)(dgrad ? Cout : Cin), Mpad = cf_mpad(M);
+    const int nkc = (int)cdiv(Kdim, CF_KC);
+    hipStream_t st = as_stream(stream);
+    const long long total = (long long)(need / sizeof(float));
+    OFASR_LAUNCH(conv_f32_prep_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, w, (float*)ws, (int)Cin, K, dgrad,
+                 M, Kdim, Mpad, total);
+    int rc = check_launch(name);
+    if (rc) return rc;
+    const int tiles_x = (int)cdiv(W, CF_TW), tiles_y = (int)cdiv(H, CF_TH);
+    dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)N, (unsigned)(Mpad / CF_MB));
+    prof_note(4.0 * (double)N * (double)H * (double)W * (double)(Cin + Cout),
+              2.0 * (double)N * (double)H * (double)W * (double)Cin * (double)Cout * K * K);
+    if (K == 5)
+        OFASR_LAUNCH(conv_f32_kernel<5>, grid, dim3(256), 0, st, (const float*)x, (const float*)ws, (float*)y, Kdim, M, Mpad,
+                     (int)H, (int)W, tiles_x, nkc);
+    else
+        OFASR_LAUNCH(conv_f32_kernel<3>, grid, dim3(256), 0, st, (const float*)x, (const float*)ws, (float*)y, Kdim, M, Mpad,
+                     (int)H, (int)W, tiles_x, nkc);
+    return check_launch(name);
+}
+
+OFASR_EXPORT int ofasr_conv2d_f32_fwd(const void* x, const float* w, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
+                                      int64_t W, int K, void* workspace, size_t workspace_bytes, void* stream) {
+    return conv2d_f32_entry("ofasr_conv2d_f32_fwd", x, w, y, N, Cin, Cout, H, W, K, 0, workspace, workspace_bytes, stream);
+}
+
+OFASR_EXPORT int ofasr_conv2d_f32_dgrad(const void* dy, const float* w, void* dx, int64_t N, int64_t Cin, int64_t Cout,
+                                        int64_t H, int64_t W, int K, void* workspace, size_t workspace_bytes, void* stream) {
+    return conv2d_f32_entry("ofasr_conv2d_f32_dgrad", dy, w, dx, N, Cin, Cout, H, W, K, 1, workspace, workspace_bytes, stream);
+}
+
+OFASR_EXPORT size_t ofasr_conv2d_f32_wgrad_workspace(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || !(K == 3 || K == 5)) return 0;
+    return (size_t)cf_nsplit(N, Cin, Cout, H, W) * Cout * Cin * K * K * sizeof(float);
+}
+
+OFASR_EXPORT int ofasr_conv2d_f32_wgrad(const void* dy, const void* x, float* dw, int64_t N, int64_t Cin, int64_t Cout,
+                                        int64_t H, int64_t W, int K, void* workspace, size_t workspace_bytes, void* stream) {
+    const char* name = "ofasr_conv2d_f32_wgrad";
+    OFASR_REQUIRE(dy && x && dw, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, OFASR_ERR_INVALID_ARG, "%s: bad shape", name);
+    OFASR_REQUIRE(K == 3 || K == 5, OFASR_ERR_UNSUPPORTED, "%s: K=%d not in {3,5}", name, K);
+    OFASR_REQUIRE(N * H * W <= (1LL << 30), OFASR_ERR_UNSUPPORTED, "%s: too large", name);
+    const size_t need = ofasr_conv2d_f32_wgrad_workspace(N, Cin, Cout, H, W, K);
+    OFASR_REQUIRE(workspace && workspace_bytes >= need, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", name,
+                  workspace_bytes, need);
+    const int nsplit = cf_nsplit(N, Cin, Cout, H, W);
+    const int tiles_x = (int)cdiv(W, CF_TW), tiles_y = (int)cdiv(H, CF_TH);
+    const int ntiles = (int)(N * tiles_x * tiles_y);
+    hipStream_t st = as_stream(stream);
+    dim3 grid((unsigned)nsplit, (unsigned)cdiv(Cout, 32), (unsigned)cdiv(Cin, 32));
+    prof_note(4.0 * (double)N * (double)H * (double)W * (double)(Cin + Cout),
+              2.0 * (double)N * (double)H * (double)W * (double)Cin * (double)Cout * K * K);
+    if (K == 5)
+        OFASR_LAUNCH(conv_f32_wgrad_kernel<5>, grid, dim3(64 * 5), 0, st, (const float*)dy, (const float*)x, (float*)workspace,
+                     (int)Cin, (int)Cout, (int)H, (int)W, tiles_x, tiles_y, ntiles, nsplit);
+    else
+        OFASR_LAUNCH(conv_f32_wgrad_kernel<3>, grid, dim3(64 * 3), 0, st, (const float*)dy, (const float*)x, (float*)workspace,
+                     (int)Cin, (int)Cout, (int)H, (int)W, tiles_x, tiles_y, ntiles, nsplit);
+    int rc = check_launch(name);
+    if (rc) return rc;
+    const long long total = (long long)Cout * Cin * K * K;
+    OFASR_LAUNCH(conv_f32_wgrad_reduce_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
+                 total, nsplit);
+    return check_launch(name);
+}

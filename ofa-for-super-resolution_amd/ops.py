@@ -680,9 +680,51 @@ HIP_CONV = True   # static ConvLayer convolutions (16-bit activations) through t
 
 def _conv_hip_ok(x, weight, stride, padding, dilation, groups):
     k = weight.shape[-1]
-    return (HIP_CONV and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and weight.dtype == torch.float32
+    return (HIP_CONV and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16, torch.float32)
+            and weight.dtype == torch.float32
             and weight.shape[2] == weight.shape[3] and k in (3, 5) and stride == (1, 1) and dilation == (1, 1)
-            and groups == 1 and padding == (k // 2, k // 2) and x.shape[3] % 8 == 0)
+            and groups == 1 and padding == (k // 2, k // 2))
+
+
+class Conv2dF32Fn(Function):
+    """nn.Conv2d of the static ConvLayer with fp32 activations: forward, input and weight gradients on the fp32 matrix
+    instruction (csrc/conv2d_f32.hip) -- the reference's arithmetic, any H / W."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        weight = weight.contiguous()
+        N, Cin, H, W = x.shape
+        Cout, _, K, _ = weight.shape
+        L = _C.lib()
+        y = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device)
+        wst, wsp, wsn = _ws(L.ofasr_conv2d_f32_workspace(Cin, Cout, K, 0), x.device)
+        with _timed("conv2d_f32_fwd_%dto%d_k%d" % (Cin, Cout, K), (x.numel() + y.numel()) * 4, 2 * N * H * W * Cin * Cout * K * K):
+            _C.check(L.ofasr_conv2d_f32_fwd(_p(x), _p(weight), _p(y), N, Cin, Cout, H, W, K, wsp, wsn, _stream()),
+                     "conv2d_f32_fwd")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        N, Cin, H, W = x.shape
+        Cout, _, K, _ = weight.shape
+        dy = dy.contiguous()
+        L = _C.lib()
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            wst2, wsp2, wsn2 = _ws(L.ofasr_conv2d_f32_wgrad_workspace(N, Cin, Cout, H, W, K), x.device)
+            _C.check(L.ofasr_conv2d_f32_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Cout, H, W, K, wsp2, wsn2, _stream()),
+                     "conv2d_f32_wgrad")
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            wst, wsp, wsn = _ws(L.ofasr_conv2d_f32_workspace(Cin, Cout, K, 1), x.device)
+            _C.check(L.ofasr_conv2d_f32_dgrad(_p(dy), _p(weight), _p(dx), N, Cin, Cout, H, W, K, wsp, wsn, _stream()),
+                     "conv2d_f32_dgrad")
+        return dx, dw
 
 
 class Conv2dFn(Function):
@@ -774,6 +816,16 @@ def conv2d(x, conv):
     if conv.bias is None and _conv_hip_ok(xa, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
         w = conv.weight
         fwd_hip, bwd_hip = _conv_policy(w.shape[1], w.shape[0], w.shape[2])
+        if xa.dtype == torch.float32:       # the reference's arithmetic: exact fp32 on the fp32 matrix instruction
+            return Conv2dF32Fn.apply(xa, w)
         if fwd_hip or CONV_FORCE_HIP:
-            return Conv2dFn.apply(xa, w, bwd_hip or CONV_FORCE_HIP)
+            # the kernel moves rows in 16-byte pieces (W % 8 == 0).  Ragged widths (Set14: 125, 62, 146 ...) are
+            # zero-padded on the right to the next multiple of 8 and the extra output columns dropped: the pad columns
+            # ARE the convolution's zero padding, so the kept columns are unchanged
+            W = xa.shape[3]
+            padw = (-W) % 8
+            if padw:
+                xa = torch.nn.functional.pad(xa, (0, padw))
+            y = Conv2dFn.apply(xa, w, bwd_hip or CONV_FORCE_HIP)
+            return y[..., :W] if padw else y
     return conv(x)

@@ -96,3 +96,60 @@ def test_conv2d_full_size_properties(shape):
     scale = float((dy.double().abs() * y2.detach().double().abs()).sum()) + 1e-9
     # y2 and dx are rounded to bf16 on store (relative 2^-9 per element, random sign): the sums agree far tighter
     assert abs(lhs - mid) <= 2e-3 * scale and abs(lhs - rhs) <= 2e-3 * scale and abs(mid - rhs) <= 2e-3 * scale
+
+
+@pytest.mark.parametrize("case", [(1, 64, 64, 9, 125, 5), (2, 3, 64, 7, 62, 5), (1, 64, 256, 5, 31, 5), (1, 64, 3, 6, 146, 5),
+                                  (1, 16, 16, 5, 13, 3)])
+def test_conv2d_ragged_width_vs_oracle(ora, case):
+    """widths that are not a multiple of 8 (Set14 LR sizes: 125, 62, 146 ...): ops.conv2d zero-pads on the right to
+    the kernel's 16-byte row granularity and drops the extra columns -- the HIP kernel serves the layer (no vendor
+    fall-back), output and gradients against the oracle conv on the unpadded tensors."""
+    ops, C = amd("ops"), amd("_C")
+    N, Cin, Cout, H, W, K = case
+    dtype = torch.bfloat16
+    r16 = lambda a: torch.from_numpy(a).to(dtype).float().numpy()
+    x = r16(det_uniform((N, Cin, H, W), "cvr/x%s" % (case,)))
+    a = float(np.sqrt(3.0 / (Cin * K * K)))
+    w = det_uniform((Cout, Cin, K, K), "cvr/w%s" % (case,), -a, a)
+    dy = r16(det_uniform((N, Cout, H, W), "cvr/dy%s" % (case,)))
+    conv = torch.nn.Conv2d(Cin, Cout, K, padding=K // 2, bias=False).to(DEV)
+    conv.weight.data.copy_(torch.from_numpy(w))
+    xt = torch.from_numpy(x).to(dtype).to(DEV).requires_grad_(True)
+    C.reset_launch_counts()
+    y = ops.conv2d(xt, conv)
+    assert C.launch_count("conv_igemm_kernel") == 1 and tuple(y.shape) == (N, Cout, H, W)
+    y_ref = ora.conv2d_fwd(x, r16(w))
+    assert_close(y.detach().float().cpu().numpy(), y_ref, 1e-2, 1e-2, "y")
+    y.backward(torch.from_numpy(dy).to(dtype).to(DEV))
+    dx_ref, dw_ref = ora.conv2d_bwd(dy, x, r16(w))
+    scale = float(np.sqrt(Cout * K * K / max(Cin * K * K, 1)))
+    assert_close(xt.grad.float().cpu().numpy(), dx_ref, 1e-2, 1e-2 * max(1.0, scale), "dx")
+    assert_close(conv.weight.grad.cpu().numpy(), dw_ref, 1e-3, 1e-3 * float(np.abs(dw_ref).max()), "dw")
+
+
+@pytest.mark.parametrize("case", CASES + [(1, 64, 64, 9, 125, 5), (2, 3, 64, 7, 62, 5), (1, 16, 16, 5, 13, 3),
+                                          (2, 64, 256, 16, 16, 5), (1, 40, 70, 6, 33, 3)])
+def test_conv2d_fp32_vs_oracle(ora, case):
+    """fp32 activations (the reference's arithmetic) on the fp32 matrix instruction (csrc/conv2d_f32.hip): forward,
+    input and weight gradients against the oracle conv (double accumulation) at fp32 tolerances, any width; the layer
+    is served by the library (no vendor kernel)."""
+    ops, C = amd("ops"), amd("_C")
+    N, Cin, Cout, H, W, K = case
+    x = det_uniform((N, Cin, H, W), "cvf/x%s" % (case,))
+    a = float(np.sqrt(3.0 / (Cin * K * K)))
+    w = det_uniform((Cout, Cin, K, K), "cvf/w%s" % (case,), -a, a)
+    dy = det_uniform((N, Cout, H, W), "cvf/dy%s" % (case,))
+    conv = torch.nn.Conv2d(Cin, Cout, K, padding=K // 2, bias=False).to(DEV)
+    conv.weight.data.copy_(torch.from_numpy(w))
+    xt = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    C.reset_launch_counts()
+    y = ops.conv2d(xt, conv)
+    assert C.launch_count("conv_f32_kernel") == 1 and y.dtype == torch.float32
+    y_ref = ora.conv2d_fwd(x, w)
+    assert_close(y.detach().cpu().numpy(), y_ref, 5e-5, 5e-6, "y")
+    y.backward(torch.from_numpy(dy).to(DEV))
+    assert C.launch_count("conv_f32_kernel") == 2 and C.launch_count("conv_f32_wgrad_kernel") == 1
+    dx_ref, dw_ref = ora.conv2d_bwd(dy, x, w)
+    scale = float(np.sqrt(Cout * K * K / max(Cin * K * K, 1)))
+    assert_close(xt.grad.cpu().numpy(), dx_ref, 5e-5, 5e-6 * max(1.0, scale), "dx")
+    assert_close(conv.weight.grad.cpu().numpy(), dw_ref, 1e-4, 2e-6 * float(np.abs(dw_ref).max()) * np.sqrt(N * H * W), "dw")

@@ -42,8 +42,25 @@ def per_kernel(rows, counter):
 
 
 def short(name):
-    m = re.search(r"ofasr::([a-z0-9_]+)", name)
-    return m.group(1) if m else name.split("(")[0][:60]
+    """the key bench.py looks a kernel up by: the demangled symbol without 'void ', the leading 'ofasr::' and the
+    parameter list -- e.g. 'bn_bwd_reduce_kernel<ofasr::bf16_t, true, 1, false>' (what ofasr_profile_read reports)"""
+    n = name.strip()
+    if n.startswith("void "):
+        n = n[5:]
+    depth, cut = 0, None
+    for i, ch in enumerate(n):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    if cut is not None:
+        n = n[:cut]
+    if n.startswith("ofasr::"):
+        n = n[7:]
+    return n
 
 
 def main():
