@@ -32,6 +32,8 @@
 // 28 v_dot2c per output = 43 k wave-instructions per CU.  DESIGN.md section 3 has the measured numbers.
 #include "ofasr_common.h"
 
+#include <atomic>
+
 namespace ofasr {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -42,22 +44,31 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x2 __attribute__((aligned(2))) u32x2_u;   // vector requests at any element boundary (ragged image widths)
+typedef u32x4 __attribute__((aligned(2))) u32x4_u;
 
 constexpr int MF_THREADS = 512;
-constexpr int MF_T = 16;          // output tile side
-constexpr int MF_WC = 24;         // window columns (image columns w0-4 .. w0+19)
-constexpr int MF_XP = 544;        // pixel pitch of the x window planes: 17 blocks of 32; 1088 B = 64 (mod 256) keeps the
-                                  // four rows of a transposing read on disjoint banks
 constexpr int MF_MC = 32;         // mid channels per chunk
 constexpr int MF_A2P = 288;       // pixel pitch of the a2 planes (576 B = 64 mod 256)
 constexpr int MF_SP = 260;        // pixel pitch of the fp32 output stage
 
-template <int K> struct MfGeom {
+// The output tile is TH x TW = 256 pixels: 16x16 (least halo), 8x32 or 4x64 (whole 128-byte lines of a 64-wide image per
+// row piece).  The window is TH+2P rows x TW+8 columns (image columns w0-4 .. w0+TW+3: 8-byte aligned quads).
+template <int K, int TH_, int TW_> struct MfGeom {
+    static_assert(TH_ * TW_ == 256 && TW_ % 8 == 0, "tile = 256 pixels, rows of 16-byte pieces");
+    static constexpr int TH = TH_, TW = TW_;
+    static constexpr int WC = TW + 8;                       // window columns
+    static constexpr int QW = WC / 4;                       // quads per window row
     static constexpr int P = K / 2;
-    static constexpr int HT = MF_T + 2 * P;                 // window rows
-    static constexpr int NPIX = HT * MF_WC;                 // window pixels (528 / 480 / 432)
+    static constexpr int HT = TH + 2 * P;                   // window rows
+    static constexpr int NPIX = HT * WC;                    // window pixels (16x16: 528 / 480 / 432)
     static constexpr int NBLK = (NPIX + 31) / 32;           // 17 / 15 / 14
     static constexpr int NB_WAVE = (NBLK + 7) / 8;          // pixel blocks per wave (3 / 2 / 2)
+    // pixel pitch of the x window planes: >= 32 NBLK and = 32 (mod 128), i.e. 64 bytes (mod 256): the four rows of a
+    // transposing read then sit on disjoint banks
+    static constexpr int XP = (NBLK * 32 - 32 + 127) / 128 * 128 + 32;
     static constexpr int A1P = NBLK * 32 + 4;               // plane pitch: = 4 (mod 8) -> 8-byte stores of 16 planes spread over banks
     static constexpr int NPAIR = (K + 1) / 2;               // tap pairs per kernel row and parity
     static constexpr int TAPS = K * NPAIR;                  // tap-pair dwords per channel: (f0 f1)(f2 f3)..(f_{K-1} 0) per kernel row
@@ -147,15 +158,16 @@ __global__ void __launch_bounds__(256) mb_fold_kernel(MfFold p, T* __restrict__ 
 }
 
 // ---- the fused block ---------------------------------------------------------------------------------------
-template <typename T, int K>
+template <typename T, int K, int TH, int TW>
 __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restrict__ x, T* __restrict__ out,
                                                               const T* __restrict__ w1f, const float* __restrict__ b1,
                                                               const uint32_t* __restrict__ taps,
                                                               const float* __restrict__ b2, const T* __restrict__ w2f,
                                                               const float* __restrict__ b3, int mid, int H, int W,
                                                               int tiles_x, int tiles_y, int residual) {
-    using G = MfGeom<K>;
+    using G = MfGeom<K, TH, TW>;
     constexpr int P = G::P, HT = G::HT, NPIX = G::NPIX, NBLK = G::NBLK, NBW = G::NB_WAVE, A1P = G::A1P, NPAIR = G::NPAIR;
+    constexpr int MF_WC = G::WC, MF_XP = G::XP, QW = G::QW;
     constexpr int A1_BYTES = MF_MC * A1P * 2, A2_BYTES = MF_MC * MF_A2P * 2;
     constexpr int X_BYTES = 64 * MF_XP * 2, S_BYTES = 64 * MF_SP * 4;
     constexpr int BODY = 2 * A1_BYTES + A2_BYTES;
@@ -175,45 +187,50 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
     b /= tiles_x;
     const int ty = b % tiles_y;
     const int n = b / tiles_y;
-    const int h0 = ty * MF_T, w0 = tx * MF_T;
+    const int h0 = ty * TH, w0 = tx * TW;
     const long long plane = (long long)H * W;
     const T* xn = x + (long long)n * 64 * plane;
 
     // ---- prologue: x window -> LDS (zeros outside the image and beyond the window)
     {
-        constexpr int QUADS = 64 * HT * (MF_WC / 4);
+        constexpr int QUADS = 64 * HT * QW;
         constexpr int NIT = (QUADS + MF_THREADS - 1) / MF_THREADS;
-        const bool w4 = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
-        if (w4) {
-            // every quad is wholly inside or outside the image: request ALL of them from clamped (always valid)
-            // addresses as straight-line code, zero the outside ones afterwards -- a load under a lane-dependent
-            // branch would end its basic block with s_waitcnt vmcnt(0): 17 serial round trips instead of one
+        if (W >= 4) {
+            // Request ALL quads from clamped (always valid) addresses as straight-line code and fix them up afterwards --
+            // a load under a lane-dependent branch would end its basic block with s_waitcnt vmcnt(0): 17 serial round
+            // trips instead of one.  Rows of a ragged width start at any 2-byte boundary: the loads are declared
+            // 2-byte aligned (global memory takes unaligned dwordx2 requests).  A quad cut by the right border is read
+            // `sh` elements early and shifted down, which also zero-fills its tail.
             uint2 v[NIT];
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int e0 = tid + it * MF_THREADS;
                 const int e = e0 < QUADS ? e0 : QUADS - 1;
-                const int c = e / (HT * 6), rem = e - c * (HT * 6);
-                const int hh = rem / 6, qd = rem - hh * 6;
+                const int c = e / (HT * QW), rem = e - c * (HT * QW);
+                const int hh = rem / QW, qd = rem - hh * QW;
                 const int gh = h0 - P + hh, gw = w0 - 4 + 4 * qd;
                 const int ghc = gh < 0 ? 0 : (gh >= H ? H - 1 : gh), gwc = gw < 0 ? 0 : (gw + 4 > W ? W - 4 : gw);
-                v[it] = *reinterpret_cast<const uint2*>(xn + (long long)c * plane + (long long)ghc * W + gwc);
+                const u32x2 q = *reinterpret_cast<const u32x2_u*>(xn + (long long)c * plane + (long long)ghc * W + gwc);
+                v[it] = make_uint2(q.x, q.y);
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int e = tid + it * MF_THREADS;
                 if (e < QUADS) {
-                    const int c = e / (HT * 6), rem = e - c * (HT * 6);
-                    const int hh = rem / 6, qd = rem - hh * 6;
+                    const int c = e / (HT * QW), rem = e - c * (HT * QW);
+                    const int hh = rem / QW, qd = rem - hh * QW;
                     const int gh = h0 - P + hh, gw = w0 - 4 + 4 * qd;
-                    const bool ok = gh >= 0 && gh < H && gw >= 0 && gw + 4 <= W;
-                    *reinterpret_cast<uint2*>(Xs + c * (MF_XP * 2) + rem * 8) = ok ? v[it] : make_uint2(0u, 0u);
+                    const bool ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
+                    const int sh = gw + 4 > W ? gw + 4 - W : 0;     // 1..3 on the one quad the right border cuts
+                    const unsigned long long q = (((unsigned long long)v[it].y << 32) | v[it].x) >> (16 * sh);
+                    *reinterpret_cast<uint2*>(Xs + c * (MF_XP * 2) + rem * 8) =
+                        ok ? make_uint2((uint32_t)q, (uint32_t)(q >> 32)) : make_uint2(0u, 0u);
                 }
             }
-        } else {   // ragged width / unaligned base: element-wise guarded loads straight into the LDS image
+        } else {   // images narrower than one quad: element-wise guarded loads straight into the LDS image
             for (int e = tid; e < QUADS; e += MF_THREADS) {
-                const int c = e / (HT * 6), rem = e - c * (HT * 6);
-                const int hh = rem / 6, qd = rem - hh * 6;
+                const int c = e / (HT * QW), rem = e - c * (HT * QW);
+                const int hh = rem / QW, qd = rem - hh * QW;
                 const int gh = h0 - P + hh, gw = w0 - 4 + 4 * qd;
                 uint2 q = make_uint2(0u, 0u);
                 if (gh >= 0 && gh < H) {
@@ -266,7 +283,7 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
         for (int i = 0; i < 16; ++i) oacc[ob][i] = 0.f;
 
     const int nchunk = mid / MF_MC;
-    const int q4 = lane & 3, row16 = lane >> 2;   // depthwise: outputs (row16, 4 q4 .. 4 q4 + 3)
+    const int q4 = lane % (TW / 4), row16 = lane / (TW / 4);   // depthwise: outputs (row16, 4 q4 .. 4 q4 + 3)
     const s16x8* w1q = reinterpret_cast<const s16x8*>(w1f) + lane;   // fragment-ordered images: [(chunk, s)][lane]
     const s16x8* w2q = reinterpret_cast<const s16x8*>(w2f) + lane;
 
@@ -319,15 +336,15 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
         const int c0 = ci * MF_MC;
         const char* src = A1 + (ci & 1) * A1_BYTES;
         constexpr int NCH = MF_MC / 8;          // channels per wave and chunk
-        constexpr int TW = G::TAPS + 1;
+        constexpr int NTW = G::TAPS + 1;
         // The taps are wave-uniform and live in scalar registers; the row of channel i+1 is requested before channel i
         // is computed (two sets fit: 29 words at K = 7), so the scalar-load latency -- the phase runs at two waves per
         // SIMD and was bound by exactly this wait -- is covered by the previous channel's products.
-        uint32_t tc[TW], tn[TW];
+        uint32_t tc[NTW], tn[NTW];
         {
             const uint32_t* tp = taps + (long long)(c0 + wave * NCH) * G::TAPROW;
 #pragma unroll
-            for (int q = 0; q < TW; ++q) tc[q] = tp[q];
+            for (int q = 0; q < NTW; ++q) tc[q] = tp[q];
         }
         // window rows of the first PF kernel rows of a channel are requested one channel ahead as well (before the
         // previous channel's a2 store: both live in the one LDS array, so the compiler will not hoist them itself)
@@ -354,7 +371,7 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
             if (i + 1 < NCH) {
                 const uint32_t* tp = taps + (long long)(c0 + cc + 1) * G::TAPROW;
 #pragma unroll
-                for (int q = 0; q < TW; ++q) tn[q] = tp[q];
+                for (int q = 0; q < NTW; ++q) tn[q] = tp[q];
                 load_rows(cc + 1, 0, PF, rn);
             }
             float o[4] = {0.f, 0.f, 0.f, 0.f};
@@ -378,10 +395,10 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
             const float bias = __uint_as_float(tc[G::TAPS]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_fmed3f(o[j] + bias, 0.f, 6.f);
-            *reinterpret_cast<uint2*>(A2 + cc * (MF_A2P * 2) + (row16 * MF_T + 4 * q4) * 2) =
+            *reinterpret_cast<uint2*>(A2 + cc * (MF_A2P * 2) + lane * 8) =   // pixel row16 * TW + 4 q4 = 4 lane
                 make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
 #pragma unroll
-            for (int q = 0; q < TW; ++q) tc[q] = tn[q];
+            for (int q = 0; q < NTW; ++q) tc[q] = tn[q];
         }
     };
 
@@ -429,43 +446,55 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
     }
     __syncthreads();
     T* on = out + (long long)n * 64 * plane;
-    const bool w8 = (W & 7) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
     constexpr int NPC = 64 * 16 * 2 / MF_THREADS;   // 16-byte row pieces per thread
-    if (w8 && h0 + MF_T <= H && w0 + MF_T <= W) {
-        // whole tile inside the image, aligned rows: straight-line code, the shortcut pieces requested together
+    if (W >= 8) {
+        // straight-line code: the shortcut pieces are requested together from clamped addresses (2-byte aligned vector
+        // requests, as in the prologue); pieces wholly inside the image leave as one 16-byte store, the piece the right
+        // border cuts element by element
         uint4 xr[NPC];
 #pragma unroll
         for (int it = 0; it < NPC; ++it) {
             const int e = tid + it * MF_THREADS;
-            const int half = e & 1, rr = (e >> 1) & 15, o = e >> 5;
+            const int half = e % (TW / 8), rr = (e / (TW / 8)) % TH, o = e >> 5;
+            const int gh = h0 + rr, gw = w0 + 8 * half;
+            const int ghc = gh < H ? gh : H - 1, gwc = gw + 8 <= W ? gw : W - 8;
             xr[it] = make_uint4(0u, 0u, 0u, 0u);
-            if (residual) xr[it] = *reinterpret_cast<const uint4*>(xn + (long long)o * plane + (long long)(h0 + rr) * W + w0 + 8 * half);
+            if (residual) {
+                const u32x4 q = *reinterpret_cast<const u32x4_u*>(xn + (long long)o * plane + (long long)ghc * W + gwc);
+                xr[it] = make_uint4(q.x, q.y, q.z, q.w);
+            }
         }
 #pragma unroll
         for (int it = 0; it < NPC; ++it) {
             const int e = tid + it * MF_THREADS;
-            const int half = e & 1, rr = (e >> 1) & 15, o = e >> 5;
-            const float* sp = St + o * MF_SP + rr * MF_T + 8 * half;
+            const int half = e % (TW / 8), rr = (e / (TW / 8)) % TH, o = e >> 5;
+            const int gh = h0 + rr, gw = w0 + 8 * half;
+            const float* sp = St + o * MF_SP + rr * TW + 8 * half;
             const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
             float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-            const uint32_t xw[4] = {xr[it].x, xr[it].y, xr[it].z, xr[it].w};
+            const long long off = (long long)o * plane + (long long)gh * W + gw;
+            if (gh < H && gw + 8 <= W) {
+                const uint32_t xw[4] = {xr[it].x, xr[it].y, xr[it].z, xr[it].w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                T lo, hi;
-                lo.v = (uint16_t)(xw[i] & 0xffffu);
-                hi.v = (uint16_t)(xw[i] >> 16);
-                v[2 * i] += to_float(lo);        // +0 when there is no shortcut (xr = 0 bits = +0.0 in both formats)
-                v[2 * i + 1] += to_float(hi);
+                for (int i = 0; i < 4; ++i) {
+                    T lo, hi;
+                    lo.v = (uint16_t)(xw[i] & 0xffffu);
+                    hi.v = (uint16_t)(xw[i] >> 16);
+                    v[2 * i] += to_float(lo);        // +0 when there is no shortcut (xr = 0 bits = +0.0 in both formats)
+                    v[2 * i + 1] += to_float(hi);
+                }
+                *reinterpret_cast<u32x4_u*>(on + off) =
+                    u32x4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
+            } else if (gh < H && gw < W) {
+                for (int i = 0; i < W - gw; ++i) on[off + i] = from_float<T>(v[i] + (residual ? to_float(xn[off + i]) : 0.f));
             }
-            *reinterpret_cast<uint4*>(on + (long long)o * plane + (long long)(h0 + rr) * W + w0 + 8 * half) =
-                make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
         }
-    } else {   // tiles cut by the image border, ragged widths: element-wise
+    } else {   // images narrower than one piece: element-wise
         for (int e = tid; e < 64 * 16 * 2; e += MF_THREADS) {
-            const int half = e & 1, rr = (e >> 1) & 15, o = e >> 5;
+            const int half = e % (TW / 8), rr = (e / (TW / 8)) % TH, o = e >> 5;
             const int gh = h0 + rr, gw = w0 + 8 * half;
             if (gh >= H || gw >= W) continue;
-            const float* sp = St + o * MF_SP + rr * MF_T + 8 * half;
+            const float* sp = St + o * MF_SP + rr * TW + 8 * half;
             const long long off = (long long)o * plane + (long long)gh * W + gw;
             for (int i = 0; i < 8 && gw + i < W; ++i) {
                 const float xv = residual ? to_float(xn[off + i]) : 0.f;
@@ -500,6 +529,24 @@ static bool mf_supported(const ofasr_mbconv_desc* d) {
            !d->bn_training[2] && d->N > 0 && d->H > 0 && d->W > 0;
 }
 
+static std::atomic<int> g_mf_tile{[] { const char* e = getenv("OFASR_MBFUSED_TILE"); return e ? atoi(e) : 0; }()};
+
+// Tile shape.  Wide tiles move whole 128-byte lines (the 16x16 tile touches 32-byte row pieces, four workgroups per
+// line) and measured 7 % (8x32) / 12 % (4x64) faster than 16x16 on images they cover without waste (N=16, mid 384:
+// 64x64 43.7 / 55.3 / 70.6 us at k = 3 / 5 / 7 with 4x64 against 49.8 / 64.2 / 76.2 with 16x16); on other sizes the pixels a
+// tile hangs over the border are computed for nothing.  Pick the best (covered fraction x speed).
+static int mf_pick_tile(int64_t H, int64_t W) {
+    static const struct { int tw; double speed; } shapes[3] = {{16, 1.0}, {32, 1.07}, {64, 1.12}};
+    int best = 16;
+    double best_score = 0.0;
+    for (const auto& sh : shapes) {
+        const int th = 256 / sh.tw;
+        const double covered = (double)(H * W) / ((double)(cdiv(W, sh.tw) * sh.tw) * (double)(cdiv(H, th) * th));
+        if (covered * sh.speed > best_score) { best = sh.tw; best_score = covered * sh.speed; }
+    }
+    return best;
+}
+
 template <typename T>
 static int mf_launch(const ofasr_mbconv_desc* d, const void* x, void* out, char* ws, const MfWs& s, hipStream_t st) {
     MfFold p;
@@ -519,18 +566,29 @@ static int mf_launch(const ofasr_mbconv_desc* d, const void* x, void* out, char*
     OFASR_LAUNCH((mb_fold_kernel<T>), dim3(96), dim3(256), 0, st, p, w1f, b1, taps, b2, w2f, b3);
     int rc = check_launch("ofasr_mbconv_infer");
     if (rc) return rc;
-    const int tiles_x = (int)cdiv(d->W, MF_T), tiles_y = (int)cdiv(d->H, MF_T);
+    // OFASR_MBFUSED_TILE=16|32|64 forces the tile width (mf_pick_tile otherwise)
+    int tw = g_mf_tile.load(std::memory_order_relaxed);
+    if (tw != 16 && tw != 32 && tw != 64) tw = mf_pick_tile(d->H, d->W);
+    const int th = 256 / tw;
+    const int tiles_x = (int)cdiv(d->W, tw), tiles_y = (int)cdiv(d->H, th);
     const long long blocks = (long long)d->N * tiles_x * tiles_y;
     OFASR_REQUIRE(blocks <= INT32_MAX, OFASR_ERR_UNSUPPORTED, "ofasr_mbconv_infer: too many tiles");
     const double px = (double)d->N * (double)d->H * (double)d->W;
     prof_note(2.0 * px * 64 * (d->residual ? 3.0 : 2.0), 2.0 * px * (2.0 * 64 * d->mid + (double)d->K * d->K * d->mid));
-#define OFASR_MF(KK)                                                                                                \
-    OFASR_LAUNCH((mb_fused_kernel<T, KK>), dim3((unsigned)blocks), dim3(MF_THREADS), 0, st, (const T*)x, (T*)out, \
-                 (const T*)w1f, (const float*)b1, (const uint32_t*)taps, (const float*)b2, (const T*)w2f,          \
+#define OFASR_MF(KK, TH, TW)                                                                                          \
+    OFASR_LAUNCH((mb_fused_kernel<T, KK, TH, TW>), dim3((unsigned)blocks), dim3(MF_THREADS), 0, st, (const T*)x,       \
+                 (T*)out, (const T*)w1f, (const float*)b1, (const uint32_t*)taps, (const float*)b2, (const T*)w2f,     \
                  (const float*)b3, (int)d->mid, (int)d->H, (int)d->W, tiles_x, tiles_y, d->residual)
-    if (d->K == 7) OFASR_MF(7);
-    else if (d->K == 5) OFASR_MF(5);
-    else OFASR_MF(3);
+#define OFASR_MFK(TH, TW)                  \
+    do {                                   \
+        if (d->K == 7) OFASR_MF(7, TH, TW); \
+        else if (d->K == 5) OFASR_MF(5, TH, TW); \
+        else OFASR_MF(3, TH, TW);          \
+    } while (0)
+    if (tw == 64) OFASR_MFK(4, 64);
+    else if (tw == 32) OFASR_MFK(8, 32);
+    else OFASR_MFK(16, 16);
+#undef OFASR_MFK
 #undef OFASR_MF
     return check_launch("ofasr_mbconv_infer");
 }
@@ -538,6 +596,8 @@ static int mf_launch(const ofasr_mbconv_desc* d, const void* x, void* out, char*
 }  // namespace ofasr
 
 using namespace ofasr;
+
+OFASR_EXPORT int ofasr_debug_mbfused_tile(int width) { return g_mf_tile.exchange(width, std::memory_order_relaxed); }
 
 OFASR_EXPORT int ofasr_mbconv_infer_supported(const ofasr_mbconv_desc* d) { return mf_supported(d) ? 1 : 0; }
 

@@ -25,12 +25,35 @@ CASES = [
     (1, 16, 16, 6, 7, torch.bfloat16), (1, 5, 9, 6, 5, torch.bfloat16), (1, 33, 125, 6, 7, torch.bfloat16),
     (2, 64, 64, 6, 7, torch.float16), (2, 64, 64, 4, 5, torch.float16), (1, 30, 31, 3, 3, torch.float16),
     (1, 36, 44, 6, 5, torch.float16),
+    # widths around the vector-request limits (W < 4: element-wise window; W < 8: element-wise rows), the sizes the tile
+    # picker sends to 8x32 (125x90) and 4x64 (24x128), a 4x64 tile cut by the right border mid-quad (W = 70)
+    (1, 9, 3, 3, 3, torch.bfloat16), (1, 9, 4, 3, 5, torch.bfloat16), (1, 6, 7, 4, 7, torch.bfloat16),
+    (1, 12, 8, 3, 3, torch.bfloat16), (1, 125, 90, 3, 7, torch.bfloat16), (1, 24, 128, 4, 5, torch.bfloat16),
+    (1, 13, 70, 3, 7, torch.float16),
 ]
+# every tile shape on sizes it would not be picked for (ofasr_debug_mbfused_tile)
+TILE_CASES = [(tw, c) for tw in (16, 32, 64) for c in (
+    (2, 64, 64, 3, 7, torch.bfloat16), (1, 45, 62, 4, 5, torch.bfloat16), (1, 30, 31, 3, 3, torch.float16),
+    (1, 21, 77, 3, 5, torch.bfloat16))]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "N%d_%dx%d_e%d_k%d_%s" % (
     c[0], c[1], c[2], c[3], c[4], "bf16" if c[5] == torch.bfloat16 else "f16"))
 def test_fused_eval_block_vs_oracle(ora, case):
+    _check_case(ora, case, None)
+
+
+@pytest.mark.parametrize("tw,case", TILE_CASES, ids=lambda v: str(v) if isinstance(v, int) else "%dx%d_k%d" % (v[1], v[2], v[4]))
+def test_fused_eval_block_every_tile_shape(ora, tw, case):
+    lib = amd("_C").lib()
+    prev = lib.ofasr_debug_mbfused_tile(tw)
+    try:
+        _check_case(ora, case, "%d, %d>" % (256 // tw, tw))
+    finally:
+        lib.ofasr_debug_mbfused_tile(prev)
+
+
+def _check_case(ora, case, want_shape):
     from oracle import composite16 as c16
     from oracle import s4_port
     N, Hh, Ww, e, K, dtype = case
@@ -48,6 +71,8 @@ def test_fused_eval_block_vs_oracle(ora, case):
     torch.cuda.synchronize()
     table = C.launch_table()
     assert sum(n for k, n in table.items() if k.startswith("mb_fused_kernel")) == 1, table
+    if want_shape:
+        assert any(k.startswith("mb_fused_kernel") and k.endswith(want_shape) for k in table), table
     assert not any(k.startswith("pw_") or k.startswith("dw_") or k.startswith("bn_") for k in table), table
     # nothing was written to the BN buffers
     for k, v in block.state_dict().items():
