@@ -477,6 +477,44 @@ __global__ void __launch_bounds__(64) bn_bwd_coef_kernel(const double* __restric
     kbi[c] = training ? (float)(sc * (double)invstd[c] * (sx / M)) : 0.f;
 }
 
+// the same from the [C][P] (sum dz, sum dz * (y - mean)) partials a producer kernel left (BwdStatOut): one wave per
+// channel, lane l folds partials l, l + 64, .. in fp64, then a fixed butterfly
+__global__ void __launch_bounds__(64) bn_bwd_coef_cp_kernel(const float2* __restrict__ partial, int P, int C, double M,
+                                                            int training, const float* __restrict__ scale,
+                                                            const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ ka,
+                                                            float* __restrict__ kbi) {
+    const int c = blockIdx.x;
+    const float2* pc = partial + (long long)c * P;
+    double s = 0.0, st = 0.0;
+    for (int q0 = threadIdx.x; q0 < P; q0 += 64 * 8) {
+        float2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = q0 + 64 * j;
+            v[j] = q < P ? pc[q] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s += (double)v[j].x;
+            st += (double)v[j].y;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off, 64);
+        st += __shfl_xor(st, off, 64);
+    }
+    if (threadIdx.x == 0) {
+        const double is = (double)invstd[c], sc = (double)scale[c];
+        const double sx = st * is;          // sum dz * xhat
+        if (dgamma) dgamma[c] = (float)sx;
+        if (dbeta) dbeta[c] = (float)s;
+        ka[c] = training ? (float)(sc * (s / M)) : 0.f;
+        kbi[c] = training ? (float)(sc * is * (sx / M)) : 0.f;
+    }
+}
+
 static int bn_parts(int64_t N, int64_t C) {
     // enough blocks to fill the chip (256 CUs x ~8 blocks), at most one image per part
     int64_t want = cdiv(2048, C > 0 ? C : 1);
@@ -786,6 +824,16 @@ OFASR_EXPORT int ofasr_bn_act_bwd(const void* dy, const void* x, const void* res
 }
 
 namespace ofasr {
+int bn_bwd_coef_cp(const float2* partial, int64_t P, int64_t C, double count, int training, const float* scale,
+                   const float* invstd, float* dgamma, float* dbeta, float* ka, float* kbi, void* stream) {
+    const char* name = "bn_bwd_coef_cp";
+    OFASR_REQUIRE(partial && scale && invstd && ka && kbi, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(P > 0 && P <= INT32_MAX && C > 0 && C <= INT32_MAX && count > 0, OFASR_ERR_INVALID_ARG, "%s: bad shape", name);
+    OFASR_LAUNCH(bn_bwd_coef_cp_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(stream), partial, (int)P, (int)C, count,
+                 training, scale, invstd, dgamma, dbeta, ka, kbi);
+    return check_launch(name);
+}
+
 int bn_bwd_reduce_coef(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
                        const float* invstd, float* dgamma, float* dbeta, float* ka, float* kbi, int64_t N, int64_t C,
                        int64_t HW, int act, int training, int dtype, void* workspace, size_t workspace_bytes,

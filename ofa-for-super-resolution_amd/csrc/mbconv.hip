@@ -480,8 +480,6 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     else
         rc = ofasr_pwconv_wgrad(t3, a2, g->dw2, d->ldw2, d->N, d->mid, d->Cout, HW, d->dtype, side_ws, s.side, sst);
     if (rc) return rc;
-    rc = ofasr_pwconv_dgrad(t3, d->w2, d->ldw2, tA, d->N, d->mid, d->Cout, HW, d->dtype, stream);
-    if (rc) return rc;
     StatView s2 = stat_view(sb, 1, d->mid, d->Cout);
     StatView s1 = stat_view(sb, 0, d->mid, d->Cout);
     // BN1 / BN2 backward without the apply pass (OFASR_MBCONV_BN_BWD_FOLD=0 restores it): the reduction pass leaves
@@ -499,10 +497,29 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
                      (reinterpret_cast<uintptr_t>(tC) & 15) == 0 &&
                      pwconv_dgrad_bx_supported(tB, y1, dx, d->residual ? dout : nullptr, d->w1, d->ldw1, d->Cin, d->mid, HW,
                                                d->dtype);
-    if (bxp) {
-        rc = bn_bwd_reduce_coef(tA, y2, s2.scale, s2.shift, s2.mean, s2.invstd, g->dgamma[1], g->dbeta[1], coef, coef + d->mid,
-                                d->N, d->mid, HW, 1, d->bn_training[1], d->dtype, workspace, s.scratch, stream);
+    // ... and without the reduction pass where the producer of da can take the sums itself (BwdStatOut;
+    // OFASR_MBCONV_BN_BWD_STAT=0 restores the pass): the project input gradient for BN2
+    static const bool bn_stat = [] { const char* e = getenv("OFASR_MBCONV_BN_BWD_STAT"); return !(e && e[0] == '0'); }();
+    const int P2b = pwconv_stat_units(d->N, d->Cout, HW);
+    const bool st2 = bxp && bn_stat && pwconv_dgrad_bstat_supported(t3, y2, tA, d->w2, d->ldw2, d->mid, d->Cout, HW, d->dtype) &&
+                     (size_t)P2b * (size_t)d->mid * sizeof(float2) <= s.stat_a;
+    if (st2) {
+        rc = pwconv_dgrad_bstat(t3, d->w2, d->ldw2, tA, d->N, d->mid, d->Cout, HW, d->dtype,
+                                BwdStatOut{y2, s2.mean, s2.scale, s2.shift, (float2*)workspace, P2b}, stream);
         if (rc) return rc;
+        rc = bn_bwd_coef_cp((const float2*)workspace, P2b, d->mid, (double)d->N * (double)HW, d->bn_training[1], s2.scale,
+                            s2.invstd, g->dgamma[1], g->dbeta[1], coef, coef + d->mid, stream);
+    } else {
+        rc = ofasr_pwconv_dgrad(t3, d->w2, d->ldw2, tA, d->N, d->mid, d->Cout, HW, d->dtype, stream);
+    }
+    if (rc) return rc;
+    if (bxp) {
+        if (!st2) {
+            rc = bn_bwd_reduce_coef(tA, y2, s2.scale, s2.shift, s2.mean, s2.invstd, g->dgamma[1], g->dbeta[1], coef,
+                                    coef + d->mid, d->N, d->mid, HW, 1, d->bn_training[1], d->dtype, workspace, s.scratch,
+                                    stream);
+            if (rc) return rc;
+        }
         rc = dwconv_dgrad_bx(tA, f, tB, d->N, d->mid, d->H, d->W, d->K, d->dtype, bx2, stream);   // also leaves dy2 in tC
         if (rc) return rc;
         rc = fork(1);   // dy2 (tC) is final

@@ -97,6 +97,18 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
 __device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
     return (uint32_t)from_float<f16_t>(lo).v | ((uint32_t)from_float<f16_t>(hi).v << 16);
 }
+// the two 16-bit values of a packed word -> fp32
+template <typename T> __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi);
+template <> __device__ __forceinline__ void unpack2<bf16_t>(uint32_t w, float& lo, float& hi) {
+    lo = __uint_as_float(w << 16);
+    hi = __uint_as_float(w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack2<f16_t>(uint32_t w, float& lo, float& hi) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 v = __builtin_bit_cast(h2, w);
+    lo = (float)v.x;
+    hi = (float)v.y;
+}
 template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
 template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack2_bf16(lo, hi); }
 template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) { return pack2_f16(lo, hi); }
@@ -144,6 +156,25 @@ struct BwdXf {
     const float* kbi;
     void* dy_out;         // where the consumer leaves dy (same shape / element type), or nullptr
 };
+// The REDUCTION pass of the same backward folded into the kernel that produces da (the gradient of the activated
+// tensor): the producer reads y at the positions it writes and leaves, per channel c and producer unit p (a pixel tile,
+// a plane slab), partial[c * P + p] = (sum dz, sum dz * (y - mean)) with dz as above and da as stored; bn_bwd_coef_cp
+// folds the P partials of a channel in fp64 in a fixed order into dgamma, dbeta, ka, kbi.  The chain loses the pass
+// "read da, read y" and its launch; the producer reads y (one tensor) more.
+struct BwdStatOut {
+    const void* y;
+    const float* mean;
+    const float* scale;
+    const float* shift;
+    float2* partial;
+    int P;
+};
+int bn_bwd_coef_cp(const float2* partial, int64_t P, int64_t C, double count, int training, const float* scale,
+                   const float* invstd, float* dgamma, float* dbeta, float* ka, float* kbi, void* stream);
+bool pwconv_dgrad_bstat_supported(const void* dy, const void* y, const void* dx, const float* w, int64_t ldw, int64_t Cin,
+                                  int64_t Cout, int64_t HW, int dtype);
+int pwconv_dgrad_bstat(const void* dy, const float* w, int64_t ldw, void* dx, int64_t N, int64_t Cin, int64_t Cout,
+                       int64_t HW, int dtype, BwdStatOut bs, void* stream);
 // reduction pass of the BN(+ReLU6) backward + a C-thread kernel that turns the partials into dgamma, dbeta and the
 // (ka, kbi) of BwdXf.  workspace: ofasr_bn_act_bwd_workspace(N, C) bytes.
 int bn_bwd_reduce_coef(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,

@@ -634,12 +634,23 @@ __device__ __forceinline__ void fo_store_w(char* Ws, const float4 (&wr)[8], bool
     }
 }
 
-template <typename T, int NSLAB, bool STAT>
+// STAT: 0 none; 1 BatchNorm statistics of the rows written (forward: StatOut); 2 BatchNorm-backward sums of the rows
+// written (the kernel then produces the gradient da of an activated tensor: BwdStatOut) -- the y values of the
+// positions a lane writes are requested before the round's MFMAs, 16 x 8 bytes mirroring its 16 stores.
+template <typename T, int NSLAB, int STAT>
 __global__ void __launch_bounds__(PW_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
-pw_fanout_slabs_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y, int HW, int tiles_per_img, StatOut so) {
+pw_fanout_slabs_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y, int HW, int tiles_per_img, StatOut so,
+                       BwdStatOut bs) {
     static_assert(Elem<T>::is16, "16-bit activations only");
     __shared__ __attribute__((aligned(16))) char Ws[FO_ROWS * Elem<T>::wrow];
     __shared__ __attribute__((aligned(16))) char Xs[64 * Elem<T>::xrow];
+    __shared__ float4 btab[STAT == 2 ? NSLAB * FO_ROWS : 1];   // per output row: mean, scale, beta = shift + mean*scale
+    if constexpr (STAT == 2) {
+        for (int i = threadIdx.x; i < NSLAB * FO_ROWS; i += PW_THREADS) {
+            const float mu = bs.mean[i], sc = bs.scale[i];
+            btab[i] = make_float4(mu, sc, fmaf(mu, sc, bs.shift[i]), 0.f);
+        }
+    }
     const int lane = lane_id();
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -680,6 +691,12 @@ pw_fanout_slabs_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y, int
         fo_store_w<T>(Ws, wr, rowmajor, tid);
         lds_barrier();                                     // Ws (and, in round 0, Xs) visible
         if (sl + 1 < NSLAB) fo_load_w<T>(wr, wv, rowmajor, m_base + FO_ROWS, tid);   // in flight over this round
+        uint2 yr[STAT == 2 ? 16 : 1];
+        if constexpr (STAT == 2) {
+            const T* ysrc = reinterpret_cast<const T*>(bs.y) + ((long long)n * wv.M + m_base + 32 * cb) * HW + px;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) yr[reg] = *reinterpret_cast<const uint2*>(ysrc + (long long)acc_row(reg, h) * HW);
+        }
         f32x16 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = zero16();
@@ -690,11 +707,41 @@ pw_fanout_slabs_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y, int
             for (int t = 0; t < 4; ++t) acc[t] = Mma16<T>::run(af, read_b_frag16(Xs, 32 * t, s, lane), acc[t]);
         }
         T* yn = y + ((long long)n * wv.M + m_base + 32 * cb) * HW + px;
+        if constexpr (STAT == 2) {
+            // sums over this lane's 4 pixels per row of dz = (0 < BN(y) < 6) ? da : 0 and dz * (y - mean), da as stored
+            float sv[16], qv[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const uint32_t w01 = pack2<T>(acc[0][reg], acc[1][reg]), w23 = pack2<T>(acc[2][reg], acc[3][reg]);
+                *reinterpret_cast<uint2*>(yn + (long long)acc_row(reg, h) * HW) = make_uint2(w01, w23);
+                const float4 cst = btab[m_base + 32 * cb + acc_row(reg, h)];
+                float da[4], yv[4];
+                unpack2<T>(w01, da[0], da[1]);
+                unpack2<T>(w23, da[2], da[3]);
+                unpack2<T>(yr[reg].x, yv[0], yv[1]);
+                unpack2<T>(yr[reg].y, yv[2], yv[3]);
+                float ss = 0.f, qq = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float tt = yv[t] - cst.x;
+                    const float pre = fmaf(tt, cst.y, cst.z);
+                    const float dz = (pre > 0.f && pre < 6.f) ? da[t] : 0.f;
+                    ss += dz;
+                    qq = fmaf(dz, tt, qq);
+                }
+                sv[reg] = ss;
+                qv[reg] = qq;
+            }
+            half_wave_row_sums(sv, qv, c);
+            const int r = m_base + 32 * cb + acc_row(half_wave_row_reg(c), h);
+            bs.partial[(long long)r * bs.P + tile] = make_float2(sv[0], qv[0]);
+        } else {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
             *reinterpret_cast<uint2*>(yn + (long long)acc_row(reg, h) * HW) =
                 make_uint2(pack2<T>(acc[0][reg], acc[1][reg]), pack2<T>(acc[2][reg], acc[3][reg]));
-        if constexpr (STAT) {
+        }
+        if constexpr (STAT == 1) {
             float sv[16], qv[16];
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
@@ -1392,9 +1439,9 @@ static void launch_gemm_v(const void* x, WView wv, void* y, int64_t HW, int tile
                 dim3 g1((unsigned)total_tiles);
 #define OFASR_FO_SLABS(NS, ST)                                                                                       \
     OFASR_LAUNCH((pw_fanout_slabs_kernel<T, NS, ST>), g1, dim3(PW_THREADS), 0, st, (const T*)x, wv, (T*)y, (int)HW, \
-                       tiles_per_img, so)
-                if (nslab == 3) { if (so.partial) OFASR_FO_SLABS(3, true); else OFASR_FO_SLABS(3, false); }
-                else { if (so.partial) OFASR_FO_SLABS(2, true); else OFASR_FO_SLABS(2, false); }
+                       tiles_per_img, so, BwdStatOut{})
+                if (nslab == 3) { if (so.partial) OFASR_FO_SLABS(3, 1); else OFASR_FO_SLABS(3, 0); }
+                else { if (so.partial) OFASR_FO_SLABS(2, 1); else OFASR_FO_SLABS(2, 0); }
 #undef OFASR_FO_SLABS
                 return;
             }
@@ -1590,6 +1637,47 @@ int pwconv_dgrad_add_bx(const void* da, const float* w, int64_t ldw, void* dx, c
 
 bool pwconv_xf_supported(const void* x, const void* y, int64_t HW, int dtype) {
     return (dtype == OFASR_F16 || dtype == OFASR_BF16) && aligned_for(x, y, HW, true);
+}
+
+// project-conv input gradient da2 = W2^T dy3 that also leaves the BN2-backward sums of what it writes (BwdStatOut):
+// the slab-walk kernel only (16-bit, aligned, vector weights, 64 gradient channels in, 256 / 384 out, HW % 128 == 0)
+bool pwconv_dgrad_bstat_supported(const void* dy, const void* y, const void* dx, const float* w, int64_t ldw, int64_t Cin,
+                                  int64_t Cout, int64_t HW, int dtype) {
+    const bool wvec = (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (ldw % 4) == 0;
+    return (dtype == OFASR_F16 || dtype == OFASR_BF16) && aligned_for(dy, dx, HW, true) &&
+           (reinterpret_cast<uintptr_t>(y) & 15) == 0 && wvec && Cout == 64 && (Cin == 2 * FO_ROWS || Cin == 3 * FO_ROWS) &&
+           HW % PW_TILE == 0;
+}
+
+template <typename T>
+static int launch_dgrad_bstat(const void* dy, WView wv, void* dx, int64_t N, int64_t HW, BwdStatOut bs, hipStream_t st) {
+    const int tiles_per_img = (int)(HW / PW_TILE);
+    const int total_tiles = (int)(N * tiles_per_img);
+    const double px = (double)N * (double)HW;
+    prof_note(2.0 * px * (wv.K + 2.0 * wv.M) + 4.0 * wv.K * wv.M, 2.0 * px * wv.K * wv.M);
+    if (wv.M == 3 * FO_ROWS)
+        OFASR_LAUNCH((pw_fanout_slabs_kernel<T, 3, 2>), dim3((unsigned)total_tiles), dim3(PW_THREADS), 0, st, (const T*)dy, wv,
+                     (T*)dx, (int)HW, tiles_per_img, StatOut{nullptr, 0}, bs);
+    else
+        OFASR_LAUNCH((pw_fanout_slabs_kernel<T, 2, 2>), dim3((unsigned)total_tiles), dim3(PW_THREADS), 0, st, (const T*)dy, wv,
+                     (T*)dx, (int)HW, tiles_per_img, StatOut{nullptr, 0}, bs);
+    return check_launch("pwconv_dgrad_bstat");
+}
+
+int pwconv_dgrad_bstat(const void* dy, const float* w, int64_t ldw, void* dx, int64_t N, int64_t Cin, int64_t Cout,
+                       int64_t HW, int dtype, BwdStatOut bs, void* stream) {
+    const char* name = "pwconv_dgrad_bstat";
+    int rc = check_pw_args(name, dy, w, dx, ldw, N, Cin, Cout, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(bs.y && bs.mean && bs.scale && bs.shift && bs.partial, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(pwconv_dgrad_bstat_supported(dy, bs.y, dx, w, ldw, Cin, Cout, HW, dtype), OFASR_ERR_UNSUPPORTED,
+                  "%s: shape outside the slab-walk kernel", name);
+    OFASR_REQUIRE(N * (HW / PW_TILE) <= INT32_MAX && bs.P == (int)(N * (HW / PW_TILE)), OFASR_ERR_INVALID_ARG,
+                  "%s: unit count %d does not match the launch", name, bs.P);
+    WView wv{w, 1, ldw, (int)Cin, (int)Cout};  // rows = input channels, reduction over output channels
+    hipStream_t st = as_stream(stream);
+    if (dtype == OFASR_F16) return launch_dgrad_bstat<f16_t>(dy, wv, dx, N, HW, bs, st);
+    return launch_dgrad_bstat<bf16_t>(dy, wv, dx, N, HW, bs, st);
 }
 
 int pwconv_stat_units(int64_t N, int64_t Cin, int64_t HW) {

@@ -140,23 +140,26 @@ def test_composite_block_16bit_vs_oracle(ora, case):
     aligned = (Hh * Ww) % 128 == 0
     if train and aligned:
         if mid in (256, 384):
-            assert ran(fwd_table, "pw_fanout_slabs_kernel<%s, %d, true>" % (T, mid // 128)) == 1, fwd_table
-            assert ran(bwd_table, "pw_fanout_slabs_kernel<%s, %d, false>" % (T, mid // 128)) == 1, bwd_table
+            assert ran(fwd_table, "pw_fanout_slabs_kernel<%s, %d, 1>" % (T, mid // 128)) == 1, fwd_table   # + BN1 stats
+            # project dgrad + the BN2-backward sums of what it writes (BwdStatOut): no reduction pass for BN2
+            assert ran(bwd_table, "pw_fanout_slabs_kernel<%s, %d, 2>" % (T, mid // 128)) == 1, bwd_table
+            assert ran(bwd_table, "bn_bwd_coef_cp_kernel") == 1, bwd_table
         assert ran(fwd_table, "pw_fanin_pipe_kernel<%s, true, true, false>" % T) == 1, fwd_table      # project: XF + fold
         # backward: BN1 / BN2 have no apply pass -- their consumers read (da, y) through the BN backward (BwdXf variants)
         assert ran(bwd_table, "pw_fanin_pipe_kernel<%s, false, true, true>" % T) == 1, bwd_table   # expand dgrad (+dout)
         assert ran(bwd_table, "pw_wgrad_direct_kernel<%s, 1>" % T) + ran(bwd_table, "pw_wgrad_direct_kernel<%s, 2>" % T) == 1
         assert ran(bwd_table, "pw_wgrad_direct_kernel<%s, 0>" % T) == 1, bwd_table
         assert ran(bwd_table, "dw_wgrad_vec_kernel<%s, %d, true>" % (T, K)) == 1, bwd_table
-        assert ran(bwd_table, "bn_bwd_reduce_kernel") == 3 and ran(bwd_table, "bn_bwd_apply_kernel") == 1
-        assert ran(bwd_table, "bn_bwd_coef_kernel") == 2
+        nstat = ran(bwd_table, "bn_bwd_coef_cp_kernel")
+        assert ran(bwd_table, "bn_bwd_reduce_kernel") == 3 - nstat and ran(bwd_table, "bn_bwd_apply_kernel") == 1
+        assert ran(bwd_table, "bn_bwd_coef_kernel") == 2 - nstat
         if K in (5, 7) and Ww in (32, 64):
             assert ran(fwd_table, "dw_mfma_kernel<%s, %d, false, true, true, false>" % (T, K)) == 1, fwd_table
             assert ran(bwd_table, "dw_mfma_kernel<%s, %d, true, false, false, true>" % (T, K)) == 1, bwd_table
         else:
             assert ran(fwd_table, "dw_vec_kernel<%s, %d, false, true, true, false>" % (T, K)) == 1, fwd_table
             assert ran(bwd_table, "dw_vec_kernel<%s, %d, true, false, false, true>" % (T, K)) == 1, bwd_table
-    folded_bwd = ran(bwd_table, "bn_bwd_coef_kernel") == 2
+    folded_bwd = ran(bwd_table, "bn_bwd_coef_kernel") + ran(bwd_table, "bn_bwd_coef_cp_kernel") == 2
     dw_mma = ran(fwd_table, "dw_mfma_kernel") > 0
     assert ran(fwd_table, "bn_stats_kernel") == 0 and ran(fwd_table, "bn_finalize") == 0 or not (train and aligned)
 
