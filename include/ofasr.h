@@ -305,9 +305,12 @@ int ofasr_bicubic_resize_u8(const void* src, void* dst, int64_t planes, int64_t 
  *   launches bracketed since the previous read (bytes / flops per DESIGN.md section 3; 0 where not annotated).
  *   Returned strings stay valid until the next call of the same function.
  *   ofasr_debug_mbfused_tile(w) forces the tile width of ofasr_mbconv_infer's kernel (16, 32 or 64; 0 = choose per
- *   image size, the default; also settable at load time by OFASR_MBFUSED_TILE) and returns the previous setting.
+ *   image size, the default; also settable at load time by OFASR_MBFUSED_TILE) and returns the previous setting;
+ *   ofasr_debug_mbfused_split(0) keeps launches with fewer tiles than CUs from spreading a tile's mid-channel chunks
+ *   over several workgroups (default 1; OFASR_MBFUSED_SPLIT=0 at load time), returns the previous setting.
  * ------------------------------------------------------------------------------------------- */
 int ofasr_debug_mbfused_tile(int width);
+int ofasr_debug_mbfused_split(int enable);
 long long ofasr_debug_launch_count(const char* substr);
 void ofasr_debug_reset_launch_counts(void);
 const char* ofasr_debug_launch_table(void);

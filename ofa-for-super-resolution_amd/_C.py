@@ -86,6 +86,7 @@ SIGNATURES = {
     "ofasr_mbconv_infer_workspace": (_c_sz, [_c_vp]),
     "ofasr_mbconv_infer": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "ofasr_debug_mbfused_tile": (_c_int, [_c_int]),
+    "ofasr_debug_mbfused_split": (_c_int, [_c_int]),
     "ofasr_debug_launch_count": (ctypes.c_longlong, [ctypes.c_char_p]),
     "ofasr_debug_reset_launch_counts": (None, []),
     "ofasr_debug_launch_table": (ctypes.c_char_p, []),

@@ -32,6 +32,7 @@
 // 28 v_dot2c per output = 43 k wave-instructions per CU.  DESIGN.md section 3 has the measured numbers.
 #include "ofasr_common.h"
 
+#include <algorithm>
 #include <atomic>
 
 namespace ofasr {
@@ -164,7 +165,8 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
                                                               const uint32_t* __restrict__ taps,
                                                               const float* __restrict__ b2, const T* __restrict__ w2f,
                                                               const float* __restrict__ b3, int mid, int H, int W,
-                                                              int tiles_x, int tiles_y, int residual) {
+                                                              int tiles_x, int tiles_y, int residual, int nsplit,
+                                                              float* __restrict__ part) {
     using G = MfGeom<K, TH, TW>;
     constexpr int P = G::P, HT = G::HT, NPIX = G::NPIX, NBLK = G::NBLK, NBW = G::NB_WAVE, A1P = G::A1P, NPAIR = G::NPAIR;
     constexpr int MF_WC = G::WC, MF_XP = G::XP, QW = G::QW;
@@ -182,7 +184,13 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, h = lane >> 5;
-    int b = blockIdx.x;
+    // nsplit > 1 (launches with fewer tiles than CUs): nsplit adjacent workgroups share a tile, each takes a contiguous
+    // range of the mid-channel chunks and leaves its partial projection in `part`; mb_fused_sum_kernel adds them up.
+    // (Folding them in the workgroup that arrives last -- arrival counter + device-scope fences -- was measured at 118 us
+    // per launch against 68 unsplit: every fence writes back and invalidates the XCD's whole L2 under the other tiles.)
+    const int tile = nsplit > 1 ? blockIdx.x / nsplit : blockIdx.x;
+    const int split = nsplit > 1 ? blockIdx.x - tile * nsplit : 0;
+    int b = tile;
     const int tx = b % tiles_x;
     b /= tiles_x;
     const int ty = b % tiles_y;
@@ -415,34 +423,47 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
     // ---- chunk pipeline: [E(i) || D(i-1)] barrier [P(i-1)] barrier
     W1 cur, nxt;
     W2 pw;
-    load_w1(0, cur);
+    const int c_lo = nsplit > 1 ? split * nchunk / nsplit : 0;
+    const int c_hi = nsplit > 1 ? (split + 1) * nchunk / nsplit : nchunk;
+    load_w1(c_lo, cur);
     nxt = cur;
-    for (int i = 0; i <= nchunk; ++i) {
-        if (i + 1 < nchunk) load_w1(i + 1, nxt);
-        if (i > 0) load_w2(i - 1, pw);
+    for (int i = c_lo; i <= c_hi; ++i) {
+        if (i + 1 < c_hi) load_w1(i + 1, nxt);
+        if (i > c_lo) load_w2(i - 1, pw);
         if (wave < 4) {
-            if (i < nchunk) expand(i, cur);
-            if (i > 0) depthwise(i - 1);
+            if (i < c_hi) expand(i, cur);
+            if (i > c_lo) depthwise(i - 1);
         } else {
-            if (i > 0) depthwise(i - 1);
-            if (i < nchunk) expand(i, cur);
+            if (i > c_lo) depthwise(i - 1);
+            if (i < c_hi) expand(i, cur);
         }
         __syncthreads();
-        if (i > 0) project(pw);
+        if (i > c_lo) project(pw);
         __syncthreads();
         cur = nxt;
     }
 
     // ---- epilogue: + b3, stage fp32 [64][SP], then 16-byte row pieces (+ shortcut)
+    if (nsplit > 1) {   // partial projection -> part[tile][split][64][256 pixels in tile order]
+        float* mine = part + ((long long)tile * nsplit + split) * (64 * 256);
 #pragma unroll
-    for (int ob = 0; ob < 2; ++ob) {
-        const int o = 32 * ob + r32;
-        const float bias = b3[o];
+        for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(St + o * MF_SP + 32 * wave + 8 * g + 4 * h) =
-                make_float4(oacc[ob][4 * g] + bias, oacc[ob][4 * g + 1] + bias, oacc[ob][4 * g + 2] + bias,
-                            oacc[ob][4 * g + 3] + bias);
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(mine + (32 * ob + r32) * 256 + 32 * wave + 8 * g + 4 * h) =
+                    make_float4(oacc[ob][4 * g], oacc[ob][4 * g + 1], oacc[ob][4 * g + 2], oacc[ob][4 * g + 3]);
+        return;
+    } else {
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            const int o = 32 * ob + r32;
+            const float bias = b3[o];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(St + o * MF_SP + 32 * wave + 8 * g + 4 * h) =
+                    make_float4(oacc[ob][4 * g] + bias, oacc[ob][4 * g + 1] + bias, oacc[ob][4 * g + 2] + bias,
+                                oacc[ob][4 * g + 3] + bias);
+        }
     }
     __syncthreads();
     T* on = out + (long long)n * 64 * plane;
@@ -504,11 +525,91 @@ __global__ void __launch_bounds__(MF_THREADS) mb_fused_kernel(const T* __restric
     }
 }
 
+// out = sum of the nsplit partial projections (fixed order) + b3 (+ x): one thread per 8-pixel row piece of a tile
+template <typename T, int TH, int TW>
+__global__ void __launch_bounds__(256) mb_fused_sum_kernel(const float* __restrict__ part, const T* __restrict__ x,
+                                                           T* __restrict__ out, const float* __restrict__ b3, int H, int W,
+                                                           int tiles_x, int tiles_y, int residual, int nsplit) {
+    const int tile = blockIdx.x >> 3;                           // 2048 pieces per tile, 8 workgroups of 256
+    const int e = ((blockIdx.x & 7) << 8) + threadIdx.x;
+    const int half = e % (TW / 8), rr = (e / (TW / 8)) % TH, o = e >> 5;
+    int b = tile;
+    const int tx = b % tiles_x;
+    b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int gh = ty * TH + rr, gw = tx * TW + 8 * half;
+    const float* src = part + (long long)tile * nsplit * (64 * 256) + o * 256 + rr * TW + 8 * half;
+    const float bias = b3[o];
+    float v[8] = {bias, bias, bias, bias, bias, bias, bias, bias};
+    for (int sp0 = 0; sp0 < nsplit; sp0 += 4) {                 // four partials requested together per round trip
+        float4 q[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sp = sp0 + j < nsplit ? sp0 + j : nsplit - 1;
+            q[j][0] = *reinterpret_cast<const float4*>(src + (long long)sp * (64 * 256));
+            q[j][1] = *reinterpret_cast<const float4*>(src + (long long)sp * (64 * 256) + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (sp0 + j < nsplit) {                             // uniform
+                v[0] += q[j][0].x; v[1] += q[j][0].y; v[2] += q[j][0].z; v[3] += q[j][0].w;
+                v[4] += q[j][1].x; v[5] += q[j][1].y; v[6] += q[j][1].z; v[7] += q[j][1].w;
+            }
+    }
+    if (gh >= H || gw >= W) return;
+    const long long off = ((long long)n * 64 + o) * H * W + (long long)gh * W + gw;
+    if (gw + 8 <= W) {
+        if (residual) {
+            const u32x4 q = *reinterpret_cast<const u32x4_u*>(x + off);
+            float lo, hi;
+            unpack2<T>(q.x, lo, hi); v[0] += lo; v[1] += hi;
+            unpack2<T>(q.y, lo, hi); v[2] += lo; v[3] += hi;
+            unpack2<T>(q.z, lo, hi); v[4] += lo; v[5] += hi;
+            unpack2<T>(q.w, lo, hi); v[6] += lo; v[7] += hi;
+        }
+        *reinterpret_cast<u32x4_u*>(out + off) =
+            u32x4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
+    } else {
+        for (int i = 0; i < W - gw; ++i) out[off + i] = from_float<T>(v[i] + (residual ? to_float(x[off + i]) : 0.f));
+    }
+}
+
 static size_t mf_align(size_t v) { return (v + 255) / 256 * 256; }
-struct MfWs {
-    size_t f, w1f, b1, taps, b2, w2f, b3, total;
+struct MfPlan {
+    int tw, th, tiles_x, tiles_y, nsplit;
+    long long tiles;
 };
-static MfWs mf_ws(int64_t mid, int K) {
+// Launches with fewer tiles than CUs split every tile's mid-channel chunks over `nsplit` workgroups: a workgroup's time
+// is nchunk x (a latency-bound chunk), so a launch that cannot fill the chip is shortened by spreading the chunks.
+// OFASR_MBFUSED_SPLIT=0 disables it.
+constexpr int MF_CUS = 256;
+static std::atomic<int> g_mf_split{[] { const char* e = getenv("OFASR_MBFUSED_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }()};
+static MfPlan mf_plan(const ofasr_mbconv_desc* d, int tw) {
+    const bool split_ok = g_mf_split.load(std::memory_order_relaxed) != 0;
+    MfPlan pl;
+    pl.tw = tw;
+    pl.th = 256 / tw;
+    pl.tiles_x = (int)cdiv(d->W, tw);
+    pl.tiles_y = (int)cdiv(d->H, pl.th);
+    pl.tiles = (long long)d->N * pl.tiles_x * pl.tiles_y;
+    const long long nchunk = d->mid / MF_MC;
+    long long ns = split_ok && pl.tiles > 0 ? MF_CUS / pl.tiles : 1;
+    if (ns > nchunk) ns = nchunk;
+    pl.nsplit = ns < 2 ? 1 : (int)ns;
+    return pl;
+}
+struct MfWs {
+    size_t f, w1f, b1, taps, b2, w2f, b3, part, total;
+};
+static MfWs mf_ws(const ofasr_mbconv_desc* d) {
+    const int64_t mid = d->mid;
+    const int K = d->K;
+    size_t n_part = 0;     // the largest of the three tile shapes (the shape is chosen at launch time)
+    for (int tw = 16; tw <= 64; tw *= 2) {
+        const MfPlan pl = mf_plan(d, tw);
+        if (pl.nsplit > 1) n_part = std::max(n_part, (size_t)pl.tiles * pl.nsplit * 64 * 256);
+    }
     MfWs s;
     const int npair = (K + 1) / 2;
     size_t o = 0;
@@ -519,6 +620,7 @@ static MfWs mf_ws(int64_t mid, int K) {
     s.b2 = o;   o += mf_align((size_t)mid * sizeof(float));
     s.w2f = o;  o += mf_align((size_t)64 * mid * 2);
     s.b3 = o;   o += mf_align(64 * sizeof(float));
+    s.part = o;     o += mf_align(n_part * sizeof(float));
     s.total = o;
     return s;
 }
@@ -563,22 +665,23 @@ static int mf_launch(const ofasr_mbconv_desc* d, const void* x, void* out, char*
     float* b2 = reinterpret_cast<float*>(ws + s.b2);
     float* b3 = reinterpret_cast<float*>(ws + s.b3);
     uint32_t* taps = reinterpret_cast<uint32_t*>(ws + s.taps);
-    OFASR_LAUNCH((mb_fold_kernel<T>), dim3(96), dim3(256), 0, st, p, w1f, b1, taps, b2, w2f, b3);
-    int rc = check_launch("ofasr_mbconv_infer");
-    if (rc) return rc;
     // OFASR_MBFUSED_TILE=16|32|64 forces the tile width (mf_pick_tile otherwise)
     int tw = g_mf_tile.load(std::memory_order_relaxed);
     if (tw != 16 && tw != 32 && tw != 64) tw = mf_pick_tile(d->H, d->W);
-    const int th = 256 / tw;
-    const int tiles_x = (int)cdiv(d->W, tw), tiles_y = (int)cdiv(d->H, th);
-    const long long blocks = (long long)d->N * tiles_x * tiles_y;
+    const MfPlan pl = mf_plan(d, tw);
+    const int tiles_x = pl.tiles_x, tiles_y = pl.tiles_y, nsplit = pl.nsplit;
+    const long long blocks = pl.tiles * nsplit;
     OFASR_REQUIRE(blocks <= INT32_MAX, OFASR_ERR_UNSUPPORTED, "ofasr_mbconv_infer: too many tiles");
+    float* part = reinterpret_cast<float*>(ws + s.part);
+    OFASR_LAUNCH((mb_fold_kernel<T>), dim3(96), dim3(256), 0, st, p, w1f, b1, taps, b2, w2f, b3);
+    int rc = check_launch("ofasr_mbconv_infer");
+    if (rc) return rc;
     const double px = (double)d->N * (double)d->H * (double)d->W;
     prof_note(2.0 * px * 64 * (d->residual ? 3.0 : 2.0), 2.0 * px * (2.0 * 64 * d->mid + (double)d->K * d->K * d->mid));
 #define OFASR_MF(KK, TH, TW)                                                                                          \
     OFASR_LAUNCH((mb_fused_kernel<T, KK, TH, TW>), dim3((unsigned)blocks), dim3(MF_THREADS), 0, st, (const T*)x,       \
                  (T*)out, (const T*)w1f, (const float*)b1, (const uint32_t*)taps, (const float*)b2, (const T*)w2f,     \
-                 (const float*)b3, (int)d->mid, (int)d->H, (int)d->W, tiles_x, tiles_y, d->residual)
+                 (const float*)b3, (int)d->mid, (int)d->H, (int)d->W, tiles_x, tiles_y, d->residual, nsplit, part)
 #define OFASR_MFK(TH, TW)                  \
     do {                                   \
         if (d->K == 7) OFASR_MF(7, TH, TW); \
@@ -590,6 +693,15 @@ static int mf_launch(const ofasr_mbconv_desc* d, const void* x, void* out, char*
     else OFASR_MFK(16, 16);
 #undef OFASR_MFK
 #undef OFASR_MF
+    rc = check_launch("ofasr_mbconv_infer");
+    if (rc || nsplit == 1) return rc;
+#define OFASR_MFS(TH, TW)                                                                                              \
+    OFASR_LAUNCH((mb_fused_sum_kernel<T, TH, TW>), dim3((unsigned)(pl.tiles * 8)), dim3(256), 0, st, (const float*)part, \
+                 (const T*)x, (T*)out, (const float*)b3, (int)d->H, (int)d->W, tiles_x, tiles_y, d->residual, nsplit)
+    if (tw == 64) OFASR_MFS(4, 64);
+    else if (tw == 32) OFASR_MFS(8, 32);
+    else OFASR_MFS(16, 16);
+#undef OFASR_MFS
     return check_launch("ofasr_mbconv_infer");
 }
 
@@ -598,12 +710,13 @@ static int mf_launch(const ofasr_mbconv_desc* d, const void* x, void* out, char*
 using namespace ofasr;
 
 OFASR_EXPORT int ofasr_debug_mbfused_tile(int width) { return g_mf_tile.exchange(width, std::memory_order_relaxed); }
+OFASR_EXPORT int ofasr_debug_mbfused_split(int enable) { return g_mf_split.exchange(enable ? 1 : 0, std::memory_order_relaxed); }
 
 OFASR_EXPORT int ofasr_mbconv_infer_supported(const ofasr_mbconv_desc* d) { return mf_supported(d) ? 1 : 0; }
 
 OFASR_EXPORT size_t ofasr_mbconv_infer_workspace(const ofasr_mbconv_desc* d) {
     if (!mf_supported(d)) return 0;
-    return mf_ws(d->mid, d->K).total;
+    return mf_ws(d).total;
 }
 
 OFASR_EXPORT int ofasr_mbconv_infer(const ofasr_mbconv_desc* d, const void* x, void* out, void* workspace,
@@ -618,7 +731,7 @@ OFASR_EXPORT int ofasr_mbconv_infer(const ofasr_mbconv_desc* d, const void* x, v
                       "%s: null BN tensor %d", name, i);
     OFASR_REQUIRE(d->chain_len >= 1 && d->chain_len <= 4 && d->ks[d->chain_len - 1] == d->K, OFASR_ERR_INVALID_ARG,
                   "%s: bad kernel chain", name);
-    const MfWs s = mf_ws(d->mid, d->K);
+    const MfWs s = mf_ws(d);
     OFASR_REQUIRE(workspace && workspace_bytes >= s.total, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", name,
                   workspace_bytes, s.total);
     char* ws = (char*)workspace;

@@ -30,6 +30,9 @@ CASES = [
     (1, 9, 3, 3, 3, torch.bfloat16), (1, 9, 4, 3, 5, torch.bfloat16), (1, 6, 7, 4, 7, torch.bfloat16),
     (1, 12, 8, 3, 3, torch.bfloat16), (1, 125, 90, 3, 7, torch.bfloat16), (1, 24, 128, 4, 5, torch.bfloat16),
     (1, 13, 70, 3, 7, torch.float16),
+    # more tiles than half the CUs: one workgroup per tile walks every chunk (the cases above have few tiles, so their
+    # chunks are spread over several workgroups whose partial projections are folded by the last to arrive)
+    (9, 64, 64, 3, 3, torch.bfloat16), (5, 64, 128, 3, 5, torch.float16),
 ]
 # every tile shape on sizes it would not be picked for (ofasr_debug_mbfused_tile)
 TILE_CASES = [(tw, c) for tw in (16, 32, 64) for c in (
@@ -51,6 +54,21 @@ def test_fused_eval_block_every_tile_shape(ora, tw, case):
         _check_case(ora, case, "%d, %d>" % (256 // tw, tw))
     finally:
         lib.ofasr_debug_mbfused_tile(prev)
+
+
+def test_fused_eval_block_split_equals_unsplit_semantics(ora):
+    """the same small call with and without spreading the chunks: both against the oracle, and close to each other
+    (the summation order of the projection differs: per-split partial sums instead of one running accumulator)"""
+    lib = amd("_C").lib()
+    case = (2, 32, 64, 6, 7, torch.bfloat16)
+    prev = lib.ofasr_debug_mbfused_split(0)
+    try:
+        y0 = _check_case(ora, case, None)
+    finally:
+        lib.ofasr_debug_mbfused_split(prev)
+    y1 = _check_case(ora, case, None)
+    d = (y0.double() - y1.double()).abs().max().item()
+    assert d <= 2.0 ** -6 * max(1.0, y0.abs().max().item()), d    # a bf16 ulp or two of the output
 
 
 def _check_case(ora, case, want_shape):
@@ -94,6 +112,7 @@ def _check_case(ora, case, want_shape):
     yr = s4_port._mb_block(sd, "blocks.0.mobile_inverted_conv.", x16.double(), K, e, [3, 5, 7], True, False, 0.1, 1e-5)
     rel = float((y.double().cpu() - yr).norm() / yr.norm())
     assert rel <= (8e-3 if dtype == torch.bfloat16 else 1.2e-3), rel
+    return y.float().cpu()
 
 
 def test_fused_eval_block_is_used_by_the_network_in_eval_mode():
