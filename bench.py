@@ -59,6 +59,7 @@ def parse(argv=None):
                                                        "(the PCIe-inclusive rate quoted in DESIGN.md; never `value`)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                                                       "the N>1 code path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--no-graphs", action="store_true", help="c5: eager launches instead of one hipGraph replay per bucket")
     ap.add_argument("--cpu-images", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args(argv)
@@ -143,7 +144,7 @@ class TrainWorkload(object):
 class EvalWorkload(object):
     """config c5: eval_ofa_net_sr.py's sub-network over the Set14 sizes, equal sizes batched (size buckets)"""
 
-    def __init__(self, M, dev, dtype, seed=0):
+    def __init__(self, M, dev, dtype, seed=0, graphs=True):
         import torch
         self.torch, self.M, self.dev = torch, M, dev
         self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtype]
@@ -161,13 +162,20 @@ class EvalWorkload(object):
         lrs = [torch.rand((1, 3, h // 4, w // 4), generator=g) for (h, w) in SET14_HR]
         self.buckets = [torch.cat(b).to(dev) for b in utils.bucket_by_size(lrs)]
         self.n_images = len(lrs)
+        # the product's eval loop (SRRunManager.validate_batched) replays one hipGraph per size bucket for 16-bit
+        # inference (graphed.py; OFASR_EVAL_GRAPHS=0 / --no-graphs: eager launches); fp32 is eager there too
+        self.graphed = None
+        if graphs and self.act_dtype != torch.float32:
+            self.graphed = importlib.import_module(PKG + ".graphed").GraphedEval(net, autocast_dtype=self.act_dtype)
 
-    def step(self, i):
+    def step(self, i, eager=False):
         torch = self.torch
         outs = []
         with torch.no_grad():
             for lr in self.buckets:
-                if self.act_dtype == torch.float32:
+                if self.graphed is not None and not eager:
+                    outs.append(self.graphed(lr))
+                elif self.act_dtype == torch.float32:
                     outs.append(self.net(lr))
                 else:
                     with torch.autocast("cuda", dtype=self.act_dtype):
@@ -339,7 +347,7 @@ def main():
 
     S = args.lr_size or (48 if args.config == "c2" else 64)
     if args.config == "c5":
-        wl = EvalWorkload(M, dev, args.dtype)
+        wl = EvalWorkload(M, dev, args.dtype, graphs=not args.no_graphs)
         per_step = wl.n_images
     else:
         wl = TrainWorkload(M, args.config, dev, args.batch, S, args.dtype, world, rank, args.h2d)
@@ -356,7 +364,9 @@ def main():
     roofline = kernel_table = pointwise = None
     if not args.no_roofline:   # every rank runs the profiled steps (they contain the gradient all-reduce); rank 0 reports
         nprof = min(args.steps, 6)
-        summ = profile_steps(M, wl.step, args.warmup + args.steps, nprof)
+        # (a replayed graph runs no host code, so the event brackets need the eager launches of the same kernels)
+        prof_step = (lambda i: wl.step(i, eager=True)) if args.config == "c5" else wl.step
+        summ = profile_steps(M, prof_step, args.warmup + args.steps, nprof)
         roofline, kernel_table, pointwise = roofline_from(summ, nprof, args.dtype)
 
     fp32 = None
@@ -401,6 +411,8 @@ def main():
             cfg.pop("params")
         else:
             cfg["images_per_pass"] = per_step
+            cfg["launch"] = ("one hipGraph replay per size bucket (graphed.GraphedEval); kernel table from eager launches"
+                             if wl.graphed is not None else "eager")
         line = {
             "metric": metric, "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

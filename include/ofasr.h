@@ -239,11 +239,22 @@ void* ofasr_side_stream(void);
  * SRRunManager.validate / eval_ofa_net_sr.py (reference sr_run_manager.py:323-393, net.eval()) and of the frozen-BN
  * teacher's forward (:417-420).  Supported: f16 / bf16 activations, Cin = Cout = 64, mid % 32 == 0, K in {3,5,7}, any
  * N, H, W (ofasr_mbconv_infer_supported; otherwise OFASR_ERR_UNSUPPORTED and the caller uses ofasr_mbconv_fwd).
- * The descriptor is ofasr_mbconv_fwd's (running statistics are only read).  workspace: the per-call folded 16-bit
- * operand images, ofasr_mbconv_infer_workspace(d) bytes.  x and out must not overlap.
+ * The descriptor is ofasr_mbconv_fwd's (running statistics are only read).  x and out must not overlap.
+ * Two steps, so that a serving loop prepares once per set of weights:
+ *   ofasr_mbconv_infer_prepare  kernel transform + BN folding -> the 16-bit operand images (a function of the weights,
+ *                               BN tensors, K and mid only; ofasr_mbconv_infer_operand_bytes(d) bytes, kept by the caller)
+ *   ofasr_mbconv_infer_run      the block on x with prepared operands; scratch (ofasr_mbconv_infer_scratch_bytes(d),
+ *                               0 for launches with at least half as many tiles as the GPU has CUs) holds the partial
+ *                               projections when a small launch spreads a tile's mid channels over several workgroups
+ * ofasr_mbconv_infer = prepare + run on one workspace of ofasr_mbconv_infer_workspace(d) bytes.
  * ------------------------------------------------------------------------------------------- */
 int ofasr_mbconv_infer_supported(const ofasr_mbconv_desc* d);
 size_t ofasr_mbconv_infer_workspace(const ofasr_mbconv_desc* d);
+size_t ofasr_mbconv_infer_operand_bytes(const ofasr_mbconv_desc* d);
+size_t ofasr_mbconv_infer_scratch_bytes(const ofasr_mbconv_desc* d);
+int ofasr_mbconv_infer_prepare(const ofasr_mbconv_desc* d, void* operands, size_t operand_bytes, void* stream);
+int ofasr_mbconv_infer_run(const ofasr_mbconv_desc* d, const void* x, void* out, const void* operands,
+                           size_t operand_bytes, void* scratch, size_t scratch_bytes, void* stream);
 int ofasr_mbconv_infer(const ofasr_mbconv_desc* d, const void* x, void* out, void* workspace, size_t workspace_bytes,
                        void* stream);
 
@@ -259,6 +270,19 @@ int ofasr_mbconv_infer(const ofasr_mbconv_desc* d, const void* x, void* out, voi
  * ragged widths on the right, which is the convolution's own padding, and drops the extra output columns).
  * ------------------------------------------------------------------------------------------- */
 size_t ofasr_conv2d_workspace(int64_t Cin, int64_t Cout, int K, int dgrad);
+/* Inference form of a whole ConvLayer (reference ofa/layers.py:120-151 in eval mode; the decoder's conv -> BN ->
+ * PixelShuffle(2) stages, ofa_mbs4.py:111-123): y = act(BN_eval(conv(x))) as ONE kernel -- the BatchNorm's affine map
+ * (scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale) is applied to the fp32 accumulators
+ * and the result rounded once; act: 0 none, 1 ReLU6, 2 PixelShuffle(2) done by the store (y is [N, Cout/4, 2H, 2W]).
+ *   ofasr_conv2d_infer_prepare  16-bit weight image + scale | shift -> operands (ofasr_conv2d_infer_operand_bytes; a
+ *                               function of the weights and BN tensors only, kept by the caller); gamma == NULL: no BN
+ *   ofasr_conv2d_infer_run      the conv on x with prepared operands; W % 8 == 0 as for ofasr_conv2d_fwd */
+size_t ofasr_conv2d_infer_operand_bytes(int64_t Cin, int64_t Cout, int K);
+int ofasr_conv2d_infer_prepare(const float* w, const float* gamma, const float* beta, const float* running_mean,
+                               const float* running_var, double eps, int64_t Cin, int64_t Cout, int K, int dtype,
+                               void* operands, size_t operand_bytes, void* stream);
+int ofasr_conv2d_infer_run(const void* x, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K,
+                           int dtype, int act, const void* operands, size_t operand_bytes, void* stream);
 int ofasr_conv2d_fwd(const void* x, const float* w, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
                      int K, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 int ofasr_conv2d_dgrad(const void* dy, const float* w, void* dx, int64_t N, int64_t Cin, int64_t Cout, int64_t H,

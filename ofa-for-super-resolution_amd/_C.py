@@ -61,6 +61,11 @@ SIGNATURES = {
     "ofasr_bn_act_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                   _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
     "ofasr_conv2d_workspace": (_c_sz, [_c_i64, _c_i64, _c_int, _c_int]),
+    "ofasr_conv2d_infer_operand_bytes": (_c_sz, [_c_i64, _c_i64, _c_int]),
+    "ofasr_conv2d_infer_prepare": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_double, _c_i64, _c_i64, _c_int, _c_int,
+                                            _c_vp, _c_sz, _c_vp]),
+    "ofasr_conv2d_infer_run": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_vp,
+                                        _c_sz, _c_vp]),
     "ofasr_conv2d_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp,
                                   _c_sz, _c_vp]),
     "ofasr_conv2d_dgrad": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp,
@@ -85,6 +90,10 @@ SIGNATURES = {
     "ofasr_mbconv_infer_supported": (_c_int, [_c_vp]),
     "ofasr_mbconv_infer_workspace": (_c_sz, [_c_vp]),
     "ofasr_mbconv_infer": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "ofasr_mbconv_infer_operand_bytes": (_c_sz, [_c_vp]),
+    "ofasr_mbconv_infer_scratch_bytes": (_c_sz, [_c_vp]),
+    "ofasr_mbconv_infer_prepare": (_c_int, [_c_vp, _c_vp, _c_sz, _c_vp]),
+    "ofasr_mbconv_infer_run": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp, _c_sz, _c_vp]),
     "ofasr_debug_mbfused_tile": (_c_int, [_c_int]),
     "ofasr_debug_mbfused_split": (_c_int, [_c_int]),
     "ofasr_debug_launch_count": (ctypes.c_longlong, [ctypes.c_char_p]),

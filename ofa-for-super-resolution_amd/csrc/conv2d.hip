@@ -56,10 +56,29 @@ __device__ __forceinline__ int cv_rec(int P, int j) { return P * 64 + ((j ^ ((P 
 
 // ---- weight image: 16-byte A fragments in consumption order [kc][ty][s][tx][row block][lane]
 //      lane (r = lane&31, h = lane>>5) holds rows 32*rb + r, k = 32*kc + 16*s + 8*h + (0..7)
+struct CvBn {
+    float* ss;            // out: scale[M] | shift[M]; nullptr: no epilogue operands wanted
+    const float* gamma;   // nullptr: no BN (scale 1, shift 0)
+    const float* beta;
+    const float* mean;
+    const float* var;
+    float eps;
+};
+
 template <typename T>
 __global__ void __launch_bounds__(256) conv_prep_kernel(const float* __restrict__ w, T* __restrict__ wimg, int Cin,
-                                                        int KS, int dgrad, int M, int Kdim, int nrb, long long total) {
+                                                        int KS, int dgrad, int M, int Kdim, int nrb, long long total,
+                                                        CvBn bn) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (bn.ss != nullptr && idx < M) {   // scale | shift of the eval-mode BN behind the conv (identity without one)
+        float sc = 1.f, sh = 0.f;
+        if (bn.gamma != nullptr) {
+            sc = bn.gamma[idx] * rsqrtf(bn.var[idx] + bn.eps);
+            sh = bn.beta[idx] - bn.mean[idx] * sc;
+        }
+        bn.ss[idx] = sc;
+        bn.ss[M + idx] = sh;
+    }
     if (idx >= total) return;
     const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
     long long t = idx >> 9;
@@ -86,10 +105,17 @@ __global__ void __launch_bounds__(256) conv_prep_kernel(const float* __restrict_
 // hide behind the staging of the window
 __device__ __forceinline__ void cv_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// inference epilogue (ofasr_conv2d_infer_run): ss = scale[M] | shift[M] of the eval-mode BatchNorm that follows the conv
+// (nullptr: plain conv output, the training path), act 0 none / 1 ReLU6 / 2 PixelShuffle(2) store ([N, M/4, 2H, 2W])
+struct CvEpi {
+    const float* ss;
+    int act;
+};
+
 template <typename T, int KS, int RB, int WM, int WP, bool ONEK>
 __global__ void __launch_bounds__(64 * WM * WP, 2) conv_igemm_kernel(const T* __restrict__ x, const T* __restrict__ wimg,
                                                                      T* __restrict__ y, int Cx, int M, int H, int W,
-                                                                     int tiles_x, int nkc, int nrb) {
+                                                                     int tiles_x, int nkc, int nrb, CvEpi epi) {
     constexpr int THREADS = 64 * WM * WP;
     constexpr int PAD = KS / 2;
     constexpr int TH = 2 * WP;
@@ -218,6 +244,51 @@ __global__ void __launch_bounds__(64 * WM * WP, 2) conv_igemm_kernel(const T* __
     }
     // ---- epilogue: lane owns 4 adjacent pixels of row (ty0 + prow) for 16 output channels per row block
     const int oy = ty0 + prow, ox = tx0 + pcol;
+    if (epi.ss != nullptr) {   // inference: y = act(conv * scale[m] + shift[m]) in fp32, one rounding (workgroup-uniform)
+        if (oy >= H || ox >= W) return;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int mb = (grb0 + rb) * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {          // registers 4q .. 4q+3 = channels mb + 8q + (0..3)
+                float v[4][4];                     // [channel j][pixel t]
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = mb + 8 * q + j;
+                    const int mc = m < M ? m : M - 1;
+                    const float sc = epi.ss[mc], sh = epi.ss[M + mc];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float r = fmaf(acc[rb][t][4 * q + j], sc, sh);
+                        if (epi.act == 1) r = fminf(fmaxf(r, 0.f), 6.f);
+                        v[j][t] = r;
+                    }
+                }
+                if (epi.act == 2) {
+                    // PixelShuffle(2) as the store: channels 4C .. 4C+3 are the (dy, dx) = (j >> 1, j & 1) sub-pixels of output
+                    // channel C; this lane holds all four for its 4 pixels -> two 16-byte rows of 8 output pixels
+                    const int m0 = mb + 8 * q;
+                    if (m0 < M) {
+                        T* dst = y + (((long long)n * (M >> 2) + (m0 >> 2)) * (2 * H) + 2 * oy) * (2 * W) + 2 * ox;
+#pragma unroll
+                        for (int dy = 0; dy < 2; ++dy)
+                            *reinterpret_cast<uint4*>(dst + (long long)dy * (2 * W)) =
+                                make_uint4(pack2<T>(v[2 * dy][0], v[2 * dy + 1][0]), pack2<T>(v[2 * dy][1], v[2 * dy + 1][1]),
+                                           pack2<T>(v[2 * dy][2], v[2 * dy + 1][2]), pack2<T>(v[2 * dy][3], v[2 * dy + 1][3]));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = mb + 8 * q + j;
+                        if (m < M)
+                            *reinterpret_cast<uint2*>(y + (((long long)n * M + m) * H + oy) * W + ox) =
+                                make_uint2(pack2<T>(v[j][0], v[j][1]), pack2<T>(v[j][2], v[j][3]));
+                    }
+                }
+            }
+        }
+        return;
+    }
     if (oy < H && ox < W) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
@@ -261,21 +332,26 @@ static CvPlan cv_plan(int64_t Cin, int64_t Cout, int K, int dgrad, int64_t N = 0
 }
 
 template <typename T>
-static int launch_conv2d(const char* name, const void* x, const float* w, void* y, int64_t N, int64_t Cin, int64_t Cout,
-                         int64_t H, int64_t W, int K, int dgrad, void* ws, hipStream_t st) {
-    const CvPlan p = cv_plan(Cin, Cout, K, dgrad, N, H, W);
+static int launch_conv_prep(const char* name, const float* w, int64_t Cin, int64_t Cout, int K, int dgrad, void* ws, CvBn bn,
+                            hipStream_t st) {
+    const CvPlan p = cv_plan(Cin, Cout, K, dgrad);
     const long long total = (long long)(p.img_bytes / 2);
     OFASR_LAUNCH((conv_prep_kernel<T>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, w, (T*)ws, (int)Cin, K,
-                       dgrad, p.M, p.Kdim, p.nrb, total);
-    int rc = check_launch(name);
-    if (rc) return rc;
+                       dgrad, p.M, p.Kdim, p.nrb, total, bn);
+    return check_launch(name);
+}
+
+template <typename T>
+static int launch_conv_run(const char* name, const void* x, const void* ws, void* y, int64_t N, int64_t Cin, int64_t Cout,
+                           int64_t H, int64_t W, int K, int dgrad, CvEpi epi, hipStream_t st) {
+    const CvPlan p = cv_plan(Cin, Cout, K, dgrad, N, H, W);
     const int tiles_x = (int)cdiv(W, CV_TW), tiles_y = (int)cdiv(H, p.th);
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)N, (unsigned)p.nslab);
     prof_note((double)sizeof(T) * (double)N * (double)H * (double)W * (double)(Cin + Cout),
               2.0 * (double)N * (double)H * (double)W * (double)Cin * (double)Cout * K * K);
 #define OFASR_CV(KS, RB, WM, WP, ONEK)                                                                                  \
     OFASR_LAUNCH((conv_igemm_kernel<T, KS, RB, WM, WP, ONEK>), grid, dim3(64 * WM * WP), 0, st, (const T*)x,         \
-                       (const T*)ws, (T*)y, p.Kdim, p.M, (int)H, (int)W, tiles_x, p.nkc, p.nrb)
+                       (const T*)ws, (T*)y, p.Kdim, p.M, (int)H, (int)W, tiles_x, p.nkc, p.nrb, epi)
 #define OFASR_CVK(KS, ONEK)                                                                                         \
     switch (p.cfg) {                                                                                                \
         case 0: OFASR_CV(KS, 2, 4, 1, ONEK); break;                                                                 \
@@ -293,6 +369,14 @@ static int launch_conv2d(const char* name, const void* x, const float* w, void* 
 #undef OFASR_CVK
 #undef OFASR_CV
     return check_launch(name);
+}
+
+template <typename T>
+static int launch_conv2d(const char* name, const void* x, const float* w, void* y, int64_t N, int64_t Cin, int64_t Cout,
+                         int64_t H, int64_t W, int K, int dgrad, void* ws, hipStream_t st) {
+    int rc = launch_conv_prep<T>(name, w, Cin, Cout, K, dgrad, ws, CvBn{}, st);
+    if (rc) return rc;
+    return launch_conv_run<T>(name, x, ws, y, N, Cin, Cout, H, W, K, dgrad, CvEpi{nullptr, 0}, st);
 }
 
 // ================================================================================= weight gradient
@@ -615,6 +699,53 @@ OFASR_EXPORT size_t ofasr_conv2d_workspace(int64_t Cin, int64_t Cout, int K, int
 OFASR_EXPORT int ofasr_conv2d_fwd(const void* x, const float* w, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
                                   int64_t W, int K, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     return conv2d_entry("ofasr_conv2d_fwd", x, w, y, N, Cin, Cout, H, W, K, dtype, 0, workspace, workspace_bytes, stream);
+}
+
+// ---- inference: conv + eval-mode BN (+ ReLU6 | PixelShuffle(2)) as one kernel, operands prepared once per set of weights
+static size_t cv_infer_bytes(int64_t Cin, int64_t Cout, int K) {
+    return (cv_plan(Cin, Cout, K, 0).img_bytes + 255) / 256 * 256 + (size_t)(2 * Cout) * sizeof(float);
+}
+OFASR_EXPORT size_t ofasr_conv2d_infer_operand_bytes(int64_t Cin, int64_t Cout, int K) {
+    if (Cin <= 0 || Cout <= 0 || !(K == 3 || K == 5)) return 0;
+    return cv_infer_bytes(Cin, Cout, K);
+}
+
+OFASR_EXPORT int ofasr_conv2d_infer_prepare(const float* w, const float* gamma, const float* beta, const float* running_mean,
+                                            const float* running_var, double eps, int64_t Cin, int64_t Cout, int K, int dtype,
+                                            void* operands, size_t operand_bytes, void* stream) {
+    const char* name = "ofasr_conv2d_infer_prepare";
+    OFASR_REQUIRE(w && operands, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(Cin > 0 && Cout > 0, OFASR_ERR_INVALID_ARG, "%s: bad shape", name);
+    OFASR_REQUIRE(dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_UNSUPPORTED, "%s: 16-bit activations only", name);
+    OFASR_REQUIRE(K == 3 || K == 5, OFASR_ERR_UNSUPPORTED, "%s: K=%d not in {3,5}", name, K);
+    OFASR_REQUIRE(gamma == nullptr || (beta && running_mean && running_var), OFASR_ERR_INVALID_ARG, "%s: incomplete BN", name);
+    OFASR_REQUIRE(operand_bytes >= cv_infer_bytes(Cin, Cout, K), OFASR_ERR_WORKSPACE, "%s: operand buffer %zu B < required %zu B",
+                  name, operand_bytes, cv_infer_bytes(Cin, Cout, K));
+    float* ss = reinterpret_cast<float*>((char*)operands + (cv_plan(Cin, Cout, K, 0).img_bytes + 255) / 256 * 256);
+    const CvBn bn{ss, gamma, beta, running_mean, running_var, (float)eps};
+    hipStream_t st = as_stream(stream);
+    if (dtype == OFASR_BF16) return launch_conv_prep<bf16_t>(name, w, Cin, Cout, K, 0, operands, bn, st);
+    return launch_conv_prep<f16_t>(name, w, Cin, Cout, K, 0, operands, bn, st);
+}
+
+OFASR_EXPORT int ofasr_conv2d_infer_run(const void* x, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
+                                        int K, int dtype, int act, const void* operands, size_t operand_bytes, void* stream) {
+    const char* name = "ofasr_conv2d_infer_run";
+    OFASR_REQUIRE(x && y && operands, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, OFASR_ERR_INVALID_ARG, "%s: bad shape", name);
+    OFASR_REQUIRE(dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_UNSUPPORTED, "%s: 16-bit activations only", name);
+    OFASR_REQUIRE(K == 3 || K == 5, OFASR_ERR_UNSUPPORTED, "%s: K=%d not in {3,5}", name, K);
+    OFASR_REQUIRE(act >= 0 && act <= 2, OFASR_ERR_INVALID_ARG, "%s: act %d not in {0 none, 1 relu6, 2 pixel shuffle}", name, act);
+    OFASR_REQUIRE(act != 2 || Cout % 4 == 0, OFASR_ERR_INVALID_ARG, "%s: PixelShuffle(2) needs Cout %% 4 == 0", name);
+    OFASR_REQUIRE(W % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0,
+                  OFASR_ERR_UNSUPPORTED, "%s: needs W %% 8 == 0 and 16-byte aligned tensors", name);
+    OFASR_REQUIRE(N <= 65535 && H * W <= (1LL << 29), OFASR_ERR_UNSUPPORTED, "%s: too large", name);
+    OFASR_REQUIRE(operand_bytes >= cv_infer_bytes(Cin, Cout, K), OFASR_ERR_WORKSPACE, "%s: operand buffer %zu B < required %zu B",
+                  name, operand_bytes, cv_infer_bytes(Cin, Cout, K));
+    const float* ss = reinterpret_cast<const float*>((const char*)operands + (cv_plan(Cin, Cout, K, 0).img_bytes + 255) / 256 * 256);
+    hipStream_t st = as_stream(stream);
+    if (dtype == OFASR_BF16) return launch_conv_run<bf16_t>(name, x, operands, y, N, Cin, Cout, H, W, K, 0, CvEpi{ss, act}, st);
+    return launch_conv_run<f16_t>(name, x, operands, y, N, Cin, Cout, H, W, K, 0, CvEpi{ss, act}, st);
 }
 
 OFASR_EXPORT int ofasr_conv2d_dgrad(const void* dy, const float* w, void* dx, int64_t N, int64_t Cin, int64_t Cout,

@@ -650,7 +650,7 @@ static int mf_pick_tile(int64_t H, int64_t W) {
 }
 
 template <typename T>
-static int mf_launch(const ofasr_mbconv_desc* d, const void* x, void* out, char* ws, const MfWs& s, hipStream_t st) {
+static int mf_fold(const ofasr_mbconv_desc* d, char* ws, const MfWs& s, hipStream_t st) {
     MfFold p;
     p.w1 = d->w1; p.ldw1 = d->ldw1; p.w2 = d->w2; p.ldw2 = d->ldw2;
     p.f = reinterpret_cast<const float*>(ws + s.f);
@@ -665,6 +665,20 @@ static int mf_launch(const ofasr_mbconv_desc* d, const void* x, void* out, char*
     float* b2 = reinterpret_cast<float*>(ws + s.b2);
     float* b3 = reinterpret_cast<float*>(ws + s.b3);
     uint32_t* taps = reinterpret_cast<uint32_t*>(ws + s.taps);
+    OFASR_LAUNCH((mb_fold_kernel<T>), dim3(96), dim3(256), 0, st, p, w1f, b1, taps, b2, w2f, b3);
+    return check_launch("ofasr_mbconv_infer_prepare");
+}
+
+template <typename T>
+static int mf_run(const ofasr_mbconv_desc* d, const void* x, void* out, char* ws, const MfWs& s, float* part,
+                  hipStream_t st) {
+    T* w1f = reinterpret_cast<T*>(ws + s.w1f);
+    T* w2f = reinterpret_cast<T*>(ws + s.w2f);
+    float* b1 = reinterpret_cast<float*>(ws + s.b1);
+    float* b2 = reinterpret_cast<float*>(ws + s.b2);
+    float* b3 = reinterpret_cast<float*>(ws + s.b3);
+    uint32_t* taps = reinterpret_cast<uint32_t*>(ws + s.taps);
+    int rc = OFASR_OK;
     // OFASR_MBFUSED_TILE=16|32|64 forces the tile width (mf_pick_tile otherwise)
     int tw = g_mf_tile.load(std::memory_order_relaxed);
     if (tw != 16 && tw != 32 && tw != 64) tw = mf_pick_tile(d->H, d->W);
@@ -672,10 +686,6 @@ static int mf_launch(const ofasr_mbconv_desc* d, const void* x, void* out, char*
     const int tiles_x = pl.tiles_x, tiles_y = pl.tiles_y, nsplit = pl.nsplit;
     const long long blocks = pl.tiles * nsplit;
     OFASR_REQUIRE(blocks <= INT32_MAX, OFASR_ERR_UNSUPPORTED, "ofasr_mbconv_infer: too many tiles");
-    float* part = reinterpret_cast<float*>(ws + s.part);
-    OFASR_LAUNCH((mb_fold_kernel<T>), dim3(96), dim3(256), 0, st, p, w1f, b1, taps, b2, w2f, b3);
-    int rc = check_launch("ofasr_mbconv_infer");
-    if (rc) return rc;
     const double px = (double)d->N * (double)d->H * (double)d->W;
     prof_note(2.0 * px * 64 * (d->residual ? 3.0 : 2.0), 2.0 * px * (2.0 * 64 * d->mid + (double)d->K * d->K * d->mid));
 #define OFASR_MF(KK, TH, TW)                                                                                          \
@@ -718,13 +728,27 @@ OFASR_EXPORT size_t ofasr_mbconv_infer_workspace(const ofasr_mbconv_desc* d) {
     if (!mf_supported(d)) return 0;
     return mf_ws(d).total;
 }
+OFASR_EXPORT size_t ofasr_mbconv_infer_operand_bytes(const ofasr_mbconv_desc* d) {
+    if (!mf_supported(d)) return 0;
+    return mf_ws(d).part;
+}
+OFASR_EXPORT size_t ofasr_mbconv_infer_scratch_bytes(const ofasr_mbconv_desc* d) {
+    if (!mf_supported(d)) return 0;
+    const MfWs s = mf_ws(d);
+    return s.total - s.part;
+}
 
-OFASR_EXPORT int ofasr_mbconv_infer(const ofasr_mbconv_desc* d, const void* x, void* out, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
-    const char* name = "ofasr_mbconv_infer";
-    OFASR_REQUIRE(d && x && out, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+static int mf_check(const char* name, const ofasr_mbconv_desc* d) {
+    OFASR_REQUIRE(d != nullptr, OFASR_ERR_INVALID_ARG, "%s: null descriptor", name);
     OFASR_REQUIRE(mf_supported(d), OFASR_ERR_UNSUPPORTED,
                   "%s: needs eval-mode BN, 16-bit activations, 64 -> mid (multiple of 32) -> 64 channels, K in {3,5,7}", name);
+    return OFASR_OK;
+}
+
+OFASR_EXPORT int ofasr_mbconv_infer_prepare(const ofasr_mbconv_desc* d, void* operands, size_t operand_bytes, void* stream) {
+    const char* name = "ofasr_mbconv_infer_prepare";
+    int rc = mf_check(name, d);
+    if (rc) return rc;
     OFASR_REQUIRE(d->w1 && d->w2 && d->wdw_max, OFASR_ERR_INVALID_ARG, "%s: null weight", name);
     for (int i = 0; i < 3; ++i)
         OFASR_REQUIRE(d->gamma[i] && d->beta[i] && d->running_mean[i] && d->running_var[i], OFASR_ERR_INVALID_ARG,
@@ -732,13 +756,43 @@ OFASR_EXPORT int ofasr_mbconv_infer(const ofasr_mbconv_desc* d, const void* x, v
     OFASR_REQUIRE(d->chain_len >= 1 && d->chain_len <= 4 && d->ks[d->chain_len - 1] == d->K, OFASR_ERR_INVALID_ARG,
                   "%s: bad kernel chain", name);
     const MfWs s = mf_ws(d);
-    OFASR_REQUIRE(workspace && workspace_bytes >= s.total, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", name,
-                  workspace_bytes, s.total);
-    char* ws = (char*)workspace;
-    int rc = ofasr_ktransform_fwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform,
-                                  reinterpret_cast<float*>(ws + s.f), d->mid, stream);
+    OFASR_REQUIRE(operands && operand_bytes >= s.part, OFASR_ERR_WORKSPACE, "%s: operand buffer %zu B < required %zu B", name,
+                  operand_bytes, s.part);
+    char* ws = (char*)operands;
+    rc = ofasr_ktransform_fwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform,
+                              reinterpret_cast<float*>(ws + s.f), d->mid, stream);
     if (rc) return rc;
     hipStream_t st = as_stream(stream);
-    if (d->dtype == OFASR_F16) return mf_launch<f16_t>(d, x, out, ws, s, st);
-    return mf_launch<bf16_t>(d, x, out, ws, s, st);
+    if (d->dtype == OFASR_F16) return mf_fold<f16_t>(d, ws, s, st);
+    return mf_fold<bf16_t>(d, ws, s, st);
+}
+
+OFASR_EXPORT int ofasr_mbconv_infer_run(const ofasr_mbconv_desc* d, const void* x, void* out, const void* operands,
+                                        size_t operand_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+    const char* name = "ofasr_mbconv_infer_run";
+    int rc = mf_check(name, d);
+    if (rc) return rc;
+    OFASR_REQUIRE(x && out, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    const MfWs s = mf_ws(d);
+    OFASR_REQUIRE(operands && operand_bytes >= s.part, OFASR_ERR_WORKSPACE, "%s: operand buffer %zu B < required %zu B", name,
+                  operand_bytes, s.part);
+    OFASR_REQUIRE(s.total == s.part || (scratch && scratch_bytes >= s.total - s.part), OFASR_ERR_WORKSPACE,
+                  "%s: scratch %zu B < required %zu B", name, scratch_bytes, s.total - s.part);
+    hipStream_t st = as_stream(stream);
+    char* ws = (char*)const_cast<void*>(operands);
+    if (d->dtype == OFASR_F16) return mf_run<f16_t>(d, x, out, ws, s, (float*)scratch, st);
+    return mf_run<bf16_t>(d, x, out, ws, s, (float*)scratch, st);
+}
+
+OFASR_EXPORT int ofasr_mbconv_infer(const ofasr_mbconv_desc* d, const void* x, void* out, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    const char* name = "ofasr_mbconv_infer";
+    int rc = mf_check(name, d);
+    if (rc) return rc;
+    const MfWs s = mf_ws(d);
+    OFASR_REQUIRE(workspace && workspace_bytes >= s.total, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", name,
+                  workspace_bytes, s.total);
+    rc = ofasr_mbconv_infer_prepare(d, workspace, s.part, stream);
+    if (rc) return rc;
+    return ofasr_mbconv_infer_run(d, x, out, workspace, s.part, (char*)workspace + s.part, s.total - s.part, stream);
 }

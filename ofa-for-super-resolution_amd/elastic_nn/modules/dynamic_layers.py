@@ -151,6 +151,7 @@ class DynamicMBConvLayer(MyModule):
     def re_organize_middle_weights(self, expand_ratio_stage=0):
         """sort the middle channels by the L1 importance of the project weights so that narrower
         expand ratios keep the most important channels (reference :156-199)."""
+        ops.clear_infer_cache()   # parameters are replaced through .data below
         w_proj = self.point_linear.conv.conv.weight.data
         importance = torch.sum(torch.abs(w_proj), dim=(0, 2, 3))
         if expand_ratio_stage > 0:

@@ -9,6 +9,8 @@ import torch.nn.functional as F
 
 def adjust_bn_according_to_idx(bn, idx):
     """permute a BatchNorm's channels (reference :67-71)"""
+    from .. import ops
+    ops.clear_infer_cache()   # .data writes are invisible to the version counters the operand cache keys on
     bn.weight.data = torch.index_select(bn.weight.data, 0, idx)
     bn.bias.data = torch.index_select(bn.bias.data, 0, idx)
     bn.running_mean.data = torch.index_select(bn.running_mean.data, 0, idx)
@@ -17,6 +19,8 @@ def adjust_bn_according_to_idx(bn, idx):
 
 def copy_bn(target_bn, src_bn):
     """copy the first target.num_features channels (reference :74-82)"""
+    from .. import ops
+    ops.clear_infer_cache()   # .data writes are invisible to the version counters the operand cache keys on
     n = target_bn.num_features
     target_bn.weight.data.copy_(src_bn.weight.data[:n])
     target_bn.bias.data.copy_(src_bn.bias.data[:n])

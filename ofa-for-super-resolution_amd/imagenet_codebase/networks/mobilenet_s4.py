@@ -24,6 +24,8 @@ class MobileNetS4(MyNetwork):
         return x
 
     def zero_last_gamma(self):
+        from ... import ops
+        ops.clear_infer_cache()
         for m in self.modules():
             if isinstance(m, MobileInvertedResidualBlock) and isinstance(m.mobile_inverted_conv, MBInvertedConvLayer) \
                     and isinstance(m.shortcut, IdentityLayer):

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from ... import distributed as dd
+from ...graphed import GraphedEval
 from ...utils import AverageMeter, bucket_by_size, device_batch, psnr_y, psnr_y_per_image
 from ..utils import get_net_info
 
@@ -293,13 +294,30 @@ class SRRunManager(object):
                 psnrs.update(psnr_y(output, images), images.size(0))
         return losses.avg, psnrs.avg
 
-    def validate_batched(self, net=None, data_loader=None, is_test=True, input_key="2x_down_image", max_batch=None):
+    def graphed(self, net):
+        """the hipGraph-replayed forward of `net` in this manager's precision (graphed.GraphedEval), one per network"""
+        cache = self.__dict__.setdefault("_graphed", {})
+        g = cache.get(id(net))
+        if g is None or g.net is not net:
+            dt = None if self.mix_prec in (None, "f32") else {"bf16": torch.bfloat16, "f16": torch.float16}[self.mix_prec]
+            g = cache[id(net)] = GraphedEval(net, autocast_dtype=dt)
+        return g
+
+    def validate_batched(self, net=None, data_loader=None, is_test=True, input_key="2x_down_image", max_batch=None,
+                         graphs=None):
         """`validate` with the loader's batch-1 items of EQUAL size run as one batch (BASELINE config 5: Set14 at
         full resolution, reference eval_ofa_net_sr.py:187-220,247-251 / sr_run_manager.py:323-393).  Loss and PSNR are
         taken per image, so the result equals `validate` on the batch-1 loader (tests/test_hip_configs.py).
+        `graphs` (default: on for 16-bit GPU inference unless OFASR_EVAL_GRAPHS=0): every size bucket's forward is captured once
+        as a hipGraph and replayed -- the per-launch host cost otherwise bounds this loop (graphed.py).
         Returns (mean loss, mean PSNR, number of forward calls)."""
         if net is None:
             net = self.net
+        if graphs is None:
+            # 16-bit inference (the one-kernel blocks / ConvLayers) by default; the fp32 path is eager unless asked
+            graphs = (os.environ.get("OFASR_EVAL_GRAPHS", "1") != "0" and str(self.device).startswith("cuda")
+                      and self.mix_prec in ("bf16", "f16"))
+        fwd = self.graphed(net) if graphs else None
         if data_loader is None:
             data_loader = self.run_config.test_loader if is_test else self.run_config.valid_loader
         net.eval()
@@ -313,8 +331,11 @@ class SRRunManager(object):
             for group in bucket_by_size(items, key=lambda it: it[input_key], max_batch=max_batch):
                 images = torch.cat([it["image"] for it in group]).to(self.device)
                 lr = torch.cat([it[input_key] for it in group]).to(self.device)
-                with self.autocast():
-                    output = net(lr).float()
+                if fwd is not None:
+                    output = fwd(lr).float()
+                else:
+                    with self.autocast():
+                        output = net(lr).float()
                 calls += 1
                 per_img = ((output - images) ** 2).mean(dim=(1, 2, 3))
                 for v in per_img.tolist():

@@ -6,6 +6,7 @@ depth-conv, SE, channel shuffle) are out of scope.
 """
 from collections import OrderedDict
 
+import torch
 import torch.nn as nn
 
 from . import ops
@@ -101,7 +102,23 @@ class ConvLayer(My2DLayer):
                                           groups=self.groups, bias=self.bias))
 
     def forward(self, x):
-        # conv (MIOpen) -> fused BatchNorm(+ReLU6) HIP passes -> remaining activation (PixelShuffle ...)
+        # inference (no grad, eval-mode BN, 16-bit activations): conv + BN (+ ReLU6 | PixelShuffle(2)) as ONE kernel with
+        # operands prepared once per set of weights (ops.conv_bn_act_infer)
+        if (ops.FUSED_INFER and x.is_cuda and not torch.is_grad_enabled() and self.ops_order == "weight_bn_act"
+                and self.dropout_rate == 0 and not (self.use_bn and self.bn.training)):
+            act = self._modules.get("act", None)
+            if act is None:
+                code, rest = ops.ACT_NONE, None
+            elif self.act_func == "relu6":
+                code, rest = ops.ACT_RELU6, None
+            elif self.act_func == "pixelshuffle" and getattr(act, "upscale_factor", None) == 2:
+                code, rest = ops.ACT_PIXEL_SHUFFLE2, None
+            else:
+                code, rest = ops.ACT_NONE, act
+            y = ops.conv_bn_act_infer(x, self.conv, self.bn if self.use_bn else None, code)
+            if y is not None:
+                return y if rest is None else rest(y)
+        # conv -> fused BatchNorm(+ReLU6) HIP passes -> remaining activation (PixelShuffle ...)
         if not (ops.FUSED_BN and self.ops_order == "weight_bn_act" and self.use_bn and self.dropout_rate == 0
                 and x.is_cuda):
             return super().forward(x)

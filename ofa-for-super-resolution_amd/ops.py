@@ -5,8 +5,10 @@ hand-written gfx950 kernel for forward AND backward.  PyTorch is plumbing here: 
 memory, the stream and the autograd graph; all arithmetic of these ops happens in
 csrc/*.hip.  There is no CPU / eager fallback: tensors must live on the GPU.
 """
+import collections
 import ctypes
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -559,10 +561,62 @@ def _mbconv_desc(x, cfg, w1, g1, b1, wdw, g2, b2, w2, g3, b3, mats):
 FUSED_INFER = os.environ.get("OFASR_MBCONV_FUSED_INFER", "1") != "0"   # the one-kernel eval-mode block (ofasr_mbconv_infer)
 
 
+# Inference operands (BN-folded weight images of the one-kernel MB block, weight images + BN scale/shift of the static
+# convs) are a function of the parameters only; in eval mode they are prepared once and kept while the tensors they were
+# built from are the SAME Python objects (weak references: an entry dies with its tensors, so a new tensor that the
+# allocator places at an old address never matches) at the same address and version (torch bumps Tensor._version on
+# every tracked in-place write: optimizer steps, load_state_dict, copy_).  Writes through `.data` are invisible to the
+# version counter, so everything in this package that rewrites weights that way (re_organize_middle_weights, init_model,
+# copy_bn) and every switch back to training mode calls clear_infer_cache().  OFASR_INFER_OPERAND_CACHE=0 prepares
+# per call.
+INFER_CACHE = os.environ.get("OFASR_INFER_OPERAND_CACHE", "1") != "0"
+_INFER_OPERANDS = collections.OrderedDict()
+_INFER_CACHE_MAX = 256
+
+
+_INFER_EPOCH = [0]
+
+
+def clear_infer_cache():
+    _INFER_OPERANDS.clear()
+    _INFER_EPOCH[0] += 1
+
+
+def infer_epoch():
+    """number of clear_infer_cache() calls so far (graphed.GraphedEval keys its captured graphs on it)"""
+    return _INFER_EPOCH[0]
+
+
+def infer_operand_buffers():
+    """the operand buffers currently cached (a captured graph that points at them keeps them alive)"""
+    return [v[0] for v in _INFER_OPERANDS.values()]
+
+
+def _infer_operands(kind, tensors, nbytes, device, prepare):
+    """the prepared operand buffer of (kind, tensors); prepare(ptr, nbytes) fills a new one on a miss"""
+    if not INFER_CACHE:
+        buf = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+        prepare(ctypes.c_void_p(buf.data_ptr()), ctypes.c_size_t(buf.numel()))
+        return buf
+    key = (kind, str(device)) + tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
+    hit = _INFER_OPERANDS.get(key)
+    if hit is not None:
+        buf, refs = hit
+        if all((r is None and t is None) or (r is not None and r() is t) for r, t in zip(refs, tensors)):
+            _INFER_OPERANDS.move_to_end(key)
+            return buf
+    buf = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    prepare(ctypes.c_void_p(buf.data_ptr()), ctypes.c_size_t(buf.numel()))
+    _INFER_OPERANDS[key] = (buf, [weakref.ref(t) if t is not None else None for t in tensors])
+    while len(_INFER_OPERANDS) > _INFER_CACHE_MAX:
+        _INFER_OPERANDS.popitem(last=False)
+    return buf
+
+
 def mbconv_infer(x, cfg, w1, g1, b1, wdw, g2, b2, w2, g3, b3, *mats):
     """the whole MB block (+ shortcut) as ONE kernel, forward only, eval-mode BN folded into the convolutions
-    (ofasr_mbconv_infer, csrc/mbfused.hip).  Returns None when the shape / dtype / BN mode is outside what the kernel
-    implements (the caller then takes the composite path)."""
+    (ofasr_mbconv_infer_prepare / _run, csrc/mbfused.hip).  Returns None when the shape / dtype / BN mode is outside
+    what the kernel implements (the caller then takes the composite path)."""
     _gpu(x, w1, wdw, w2)
     if x.dtype not in (torch.float16, torch.bfloat16):
         return None
@@ -573,9 +627,20 @@ def mbconv_infer(x, cfg, w1, g1, b1, wdw, g2, b2, w2, g3, b3, *mats):
     if not L.ofasr_mbconv_infer_supported(dp):
         return None
     out = torch.empty((x.shape[0], cfg["out"], x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device)
-    wst, wsp, wsn = _ws(L.ofasr_mbconv_infer_workspace(dp), x.device)
+    bns = cfg["bns"]
+    kind = ("mb", x.dtype, cfg["mid"], cfg["out"], cfg["K"], tuple(cfg["chain"]), int(d.transform),
+            tuple(float(bn.eps) for bn in bns))
+    tensors = (w1, g1, b1, wdw, g2, b2, w2, g3, b3) + tuple(mats) + tuple(t for bn in bns
+                                                                         for t in (bn.running_mean, bn.running_var))
+
+    def prepare(ptr, nbytes):
+        _C.check(L.ofasr_mbconv_infer_prepare(dp, ptr, nbytes, _stream()), "mbconv_infer_prepare")
+
     with _timed("mbconv_infer"):
-        _C.check(L.ofasr_mbconv_infer(dp, _p(x), _p(out), wsp, wsn, _stream()), "mbconv_infer")
+        opnd = _infer_operands(kind, tensors, L.ofasr_mbconv_infer_operand_bytes(dp), x.device, prepare)
+        sst, ssp, ssn = _ws(L.ofasr_mbconv_infer_scratch_bytes(dp), x.device)
+        _C.check(L.ofasr_mbconv_infer_run(dp, _p(x), _p(out), _p(opnd), ctypes.c_size_t(opnd.numel()), ssp, ssn, _stream()),
+                 "mbconv_infer_run")
     return out
 
 
@@ -799,6 +864,52 @@ class Conv2dFn(Function):
         if side is not None:
             cur.wait_stream(side)
         return dx, dw, None
+
+
+ACT_PIXEL_SHUFFLE2 = 2   # ofasr_conv2d_infer_run's act codes: 0 none, 1 ReLU6 (= ACT_RELU6), 2 PixelShuffle(2) store
+
+
+def conv_bn_act_infer(x, conv, bn, act):
+    """eval-mode ConvLayer as ONE kernel (ofasr_conv2d_infer_prepare / _run): act(BN_eval(conv(x))), act in
+    {ACT_NONE, ACT_RELU6, ACT_PIXEL_SHUFFLE2}; bn may be None.  Returns None when the conv is outside what the kernel
+    implements (the caller then composes conv2d + bn_act + activation)."""
+    w = conv.weight
+    if torch.is_autocast_enabled() and x.is_cuda and x.dtype == torch.float32:
+        x = x.to(torch.get_autocast_dtype("cuda"))
+    if (not x.is_cuda or x.dtype not in (torch.float16, torch.bfloat16) or conv.bias is not None or w.dtype != torch.float32
+            or not _conv_hip_ok(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
+            or (bn is not None and (bn.training or bn.weight is None or not bn.track_running_stats))):
+        return None
+    N, Cin, H, W = x.shape
+    Cout, _, K, _ = w.shape
+    if act == ACT_PIXEL_SHUFFLE2 and Cout % 4:
+        return None
+    L = _C.lib()
+    xa = x.contiguous()
+    padw = (-W) % 8          # ragged widths: zero columns on the right ARE the convolution's padding (see conv2d)
+    if padw:
+        xa = torch.nn.functional.pad(xa, (0, padw))
+    Wp = W + padw
+    tensors = (w,) + ((bn.weight, bn.bias, bn.running_mean, bn.running_var) if bn is not None else ())
+
+    def prepare(ptr, nbytes):
+        g = [_p(t) for t in tensors[1:]] if bn is not None else [None] * 4
+        _C.check(L.ofasr_conv2d_infer_prepare(_p(w), g[0], g[1], g[2], g[3], float(bn.eps) if bn is not None else 0.0, Cin,
+                                              Cout, K, _dt(xa), ptr, nbytes, _stream()), "conv2d_infer_prepare")
+
+    kind = ("conv", xa.dtype, Cin, Cout, K, float(bn.eps) if bn is not None else None)
+    opnd = _infer_operands(kind, tensors, L.ofasr_conv2d_infer_operand_bytes(Cin, Cout, K), xa.device, prepare)
+    if act == ACT_PIXEL_SHUFFLE2:
+        y = torch.empty((N, Cout // 4, 2 * H, 2 * Wp), dtype=xa.dtype, device=xa.device)
+    else:
+        y = torch.empty((N, Cout, H, Wp), dtype=xa.dtype, device=xa.device)
+    with _timed("conv2d_infer_%dto%d_k%d" % (Cin, Cout, K), (xa.numel() + y.numel()) * xa.element_size(),
+                2 * N * H * Wp * Cin * Cout * K * K):
+        _C.check(L.ofasr_conv2d_infer_run(_p(xa), _p(y), N, Cin, Cout, H, Wp, K, _dt(xa), int(act), _p(opnd),
+                                          ctypes.c_size_t(opnd.numel()), _stream()), "conv2d_infer_run")
+    if padw:
+        y = y[..., :(2 * W if act == ACT_PIXEL_SHUFFLE2 else W)]
+    return y
 
 
 def _conv_policy(cin, cout, k):

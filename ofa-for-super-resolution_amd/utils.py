@@ -247,6 +247,19 @@ class AverageMeter(object):
 class MyModule(nn.Module):
     """reference ofa/utils.py:78-93"""
 
+    # The inference operand cache (ops.py: BN-folded weight images kept across eval-mode forwards) is dropped whenever
+    # weights may change behind autograd's version counters: back to training mode, a state dict loaded, a re-init.
+    def train(self, mode=True):
+        if mode:
+            from . import ops
+            ops.clear_infer_cache()
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        from . import ops
+        ops.clear_infer_cache()
+        return super().load_state_dict(*args, **kwargs)
+
     def forward(self, x):
         raise NotImplementedError
 
@@ -284,6 +297,8 @@ class MyNetwork(MyModule):
     def init_model(self, model_init):
         """he_fout / he_fin for convs, BN gamma=1 beta=0 (reference ofa/utils.py:134-155).  Transform
         matrices are not nn.Conv2d and keep their identity init."""
+        from . import ops
+        ops.clear_infer_cache()
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 kk = m.kernel_size[0] * m.kernel_size[1]

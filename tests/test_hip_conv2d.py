@@ -153,3 +153,76 @@ def test_conv2d_fp32_vs_oracle(ora, case):
     scale = float(np.sqrt(Cout * K * K / max(Cin * K * K, 1)))
     assert_close(xt.grad.cpu().numpy(), dx_ref, 5e-5, 5e-6 * max(1.0, scale), "dx")
     assert_close(conv.weight.grad.cpu().numpy(), dw_ref, 1e-4, 2e-6 * float(np.abs(dw_ref).max()) * np.sqrt(N * H * W), "dw")
+
+
+INFER_CASES = [
+    # N, Cin, Cout, H, W, K, act_func, use_bn
+    (2, 64, 256, 6, 64, 5, "pixelshuffle", True),    # decoder stage: conv -> BN -> PixelShuffle(2) in one kernel
+    (1, 64, 256, 5, 125, 5, "pixelshuffle", True),   # ragged Set14 width
+    (1, 3, 64, 7, 72, 5, "relu6", True),             # stem
+    (2, 64, 64, 4, 128, 5, None, True),
+    (1, 64, 3, 6, 146, 5, None, False),              # head without BN, ragged
+    (1, 64, 128, 5, 40, 3, "relu", True),            # an activation the epilogue does not know: applied afterwards
+]
+
+
+@pytest.mark.parametrize("case", INFER_CASES, ids=lambda c: "%dx%d_%dto%d_k%d_%s%s" % (c[3], c[4], c[1], c[2], c[5], c[6],
+                                                                                       "" if c[7] else "_nobn"))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv_layer_inference_one_kernel_vs_oracle(ora, case, dtype):
+    """eval-mode ConvLayer = conv -> BN(running statistics) -> ReLU6 | PixelShuffle(2) (reference ofa/layers.py:120-151,
+    ofa_mbs4.py:111-123) as ONE kernel (ofasr_conv2d_infer_run) against the oracle's conv / BN / PixelShuffle in
+    double on the same 16-bit inputs and 16-bit-rounded weights; one rounding of the result."""
+    layers, C = amd("layers"), amd("_C")
+    N, Cin, Cout, H, W, K, act, use_bn = case
+    r16 = lambda a: torch.from_numpy(a).to(dtype).float().numpy()
+    x = r16(det_uniform((N, Cin, H, W), "cvi/x%s" % (case,)))
+    a = float(np.sqrt(3.0 / (Cin * K * K)))
+    w = det_uniform((Cout, Cin, K, K), "cvi/w%s" % (case,), -a, a)
+    layer = layers.ConvLayer(Cin, Cout, kernel_size=K, use_bn=use_bn, act_func=act).to(DEV).eval()
+    layer.conv.weight.data.copy_(torch.from_numpy(w))
+    if use_bn:
+        g = det_uniform((Cout,), "cvi/g%s" % (case,), 0.5, 1.5)
+        b = det_uniform((Cout,), "cvi/b%s" % (case,), -0.5, 0.5)
+        rm = det_uniform((Cout,), "cvi/rm%s" % (case,), -0.3, 0.3)
+        rv = det_uniform((Cout,), "cvi/rv%s" % (case,), 0.2, 1.2)
+        for t, v in ((layer.bn.weight, g), (layer.bn.bias, b), (layer.bn.running_mean, rm), (layer.bn.running_var, rv)):
+            t.data.copy_(torch.from_numpy(v))
+    amd("ops").clear_infer_cache()
+    xt = torch.from_numpy(x).to(dtype).to(DEV)
+    C.reset_launch_counts()
+    with torch.no_grad():
+        y = layer(xt)
+    table = C.launch_table()
+    assert C.launch_count("conv_igemm_kernel") == 1 and C.launch_count("conv_prep_kernel") == 1, table
+    assert C.launch_count("bn_") == 0 and C.launch_count("ps_") == 0, table
+
+    ref = ora.conv2d_fwd(x, r16(w)).astype(np.float64)
+    if use_bn:
+        sc = g.astype(np.float64) / np.sqrt(rv.astype(np.float64) + layer.bn.eps)
+        ref = ref * sc.reshape(1, -1, 1, 1) + (b - rm * sc).reshape(1, -1, 1, 1)
+    if act == "relu6":
+        ref = np.clip(ref, 0.0, 6.0)
+    elif act == "relu":
+        ref = np.maximum(ref, 0.0)
+    elif act == "pixelshuffle":
+        ref = ora.pixel_shuffle(ref.astype(np.float32), 2).astype(np.float64)
+    assert tuple(y.shape) == ref.shape
+    rt = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    assert_close(y.float().cpu().numpy(), ref.astype(np.float32), rt, rt, "y")
+
+    # second call: the prepared operands are reused (no weight-image launch), same bits
+    C.reset_launch_counts()
+    with torch.no_grad():
+        y2 = layer(xt)
+    assert C.launch_count("conv_prep_kernel") == 0 and C.launch_count("conv_igemm_kernel") == 1
+    assert torch.equal(y, y2)
+    # a tracked in-place write to a weight invalidates them
+    with torch.no_grad():
+        layer.conv.weight.mul_(2.0)
+    C.reset_launch_counts()
+    with torch.no_grad():
+        y3 = layer(xt)
+    assert C.launch_count("conv_prep_kernel") == 1
+    if not use_bn and act is None:
+        assert_close(y3.float().cpu().numpy(), 2.0 * ref.astype(np.float32), rt, 2 * rt, "y after the weight update")

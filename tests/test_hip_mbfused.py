@@ -151,3 +151,42 @@ def test_fused_eval_block_is_used_by_the_network_in_eval_mode():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         net(x)
     assert C.launch_count("mb_fused_kernel") == 0
+
+
+def test_fused_eval_block_operands_prepared_once():
+    """the BN-folded operand images are a function of the weights only: a second eval-mode forward of the same block
+    launches neither the kernel transform nor the fold kernel and returns the same bits; an optimizer-style in-place
+    update, a re-organisation of the middle channels and a return to training mode each invalidate them."""
+    C, ops = amd("_C"), amd("ops")
+    block, layer = _make_block(77)
+    block.to(DEV).eval()
+    layer.active_kernel_size, layer.active_expand_ratio = 5, 4
+    x = torch.randn(2, 64, 24, 40, device=DEV).bfloat16()
+    ops.clear_infer_cache()
+
+    def run():
+        C.reset_launch_counts()
+        with torch.no_grad():
+            y = block(x)
+        return y, C.launch_count("mb_fold_kernel"), C.launch_count("kt_fwd_kernel"), C.launch_count("mb_fused_kernel")
+
+    y0, nf, nk, nm = run()
+    assert (nf, nk, nm) == (1, 1, 1)
+    y1, nf, nk, nm = run()
+    assert (nf, nk, nm) == (0, 0, 1) and torch.equal(y0, y1)
+    with torch.no_grad():
+        layer.depth_conv.conv.conv.weight.add_(0.05)
+    y2, nf, nk, nm = run()
+    assert (nf, nk, nm) == (1, 1, 1) and not torch.equal(y0, y2)
+    layer.re_organize_middle_weights()
+    _, nf, _, _ = run()
+    assert nf == 1
+    block.train()
+    block.eval()
+    _, nf2, _, _ = run()
+    y3, nf3, _, _ = run()
+    assert nf2 == 1 and nf3 == 0
+    # another active kernel size of the same block is another set of operands
+    layer.active_kernel_size = 3
+    _, nf, nk, _ = run()
+    assert (nf, nk) == (1, 1)
