@@ -335,6 +335,10 @@ int ofasr_bicubic_resize_u8(const void* src, void* dst, int64_t planes, int64_t 
  * ------------------------------------------------------------------------------------------- */
 int ofasr_debug_mbfused_tile(int width);
 int ofasr_debug_mbfused_split(int enable);
+/*   ofasr_debug_mbconv_bn_bwd_stat(1): ofasr_mbconv_bwd lets the project input gradient take the BN2-backward sums of
+ *   what it writes instead of running the reduction pass (default 0: measured 1 % slower in the training step;
+ *   OFASR_MBCONV_BN_BWD_STAT=1 at load time); returns the previous setting. */
+int ofasr_debug_mbconv_bn_bwd_stat(int enable);
 long long ofasr_debug_launch_count(const char* substr);
 void ofasr_debug_reset_launch_counts(void);
 const char* ofasr_debug_launch_table(void);

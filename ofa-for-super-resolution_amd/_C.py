@@ -96,6 +96,7 @@ SIGNATURES = {
     "ofasr_mbconv_infer_run": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp, _c_sz, _c_vp]),
     "ofasr_debug_mbfused_tile": (_c_int, [_c_int]),
     "ofasr_debug_mbfused_split": (_c_int, [_c_int]),
+    "ofasr_debug_mbconv_bn_bwd_stat": (_c_int, [_c_int]),
     "ofasr_debug_launch_count": (ctypes.c_longlong, [ctypes.c_char_p]),
     "ofasr_debug_reset_launch_counts": (None, []),
     "ofasr_debug_launch_table": (ctypes.c_char_p, []),

@@ -25,6 +25,8 @@ namespace ofasr {
 typedef __attribute__((ext_vector_type(16))) float cf_f32x16;
 
 constexpr int CF_TH = 4, CF_TW = 32, CF_KC = 16, CF_MB = 64;
+constexpr int CF_WG_RB = 1;    // weight gradient: 32-row output-channel blocks per wave
+constexpr int CF_WG_TH = 4;    // weight gradient: rows of the pixel tile staged per barrier round
 
 // weight image [kc][ty][tx][kk = 16][m = Mpad] fp32 (zeros beyond the slice)
 __global__ void __launch_bounds__(256) conv_f32_prep_kernel(const float* __restrict__ w, float* __restrict__ wimg, int Cin,
@@ -120,28 +122,125 @@ __global__ void __launch_bounds__(64 * KS) conv_f32_wgrad_kernel(const float* __
                                                                  float* __restrict__ part, int Cin, int Cout, int H, int W,
                                                                  int tiles_x, int tiles_y, int ntiles, int nsplit) {
     constexpr int P = KS / 2, THREADS = 64 * KS;
-    constexpr int RH = CF_TH + KS - 1, RW = CF_TW + KS - 1;
-    constexpr int GPL = CF_TH * CF_TW + 1;                  // dY plane pitch: bank = (co + pixel) % 32 -> conflict-free A reads
+    constexpr int RH = CF_WG_TH + KS - 1, RW = CF_TW + KS - 1;
+    constexpr int GPL = CF_WG_TH * CF_TW + 1;                  // dY plane pitch: bank = (co + pixel) % 32 -> conflict-free A reads
     constexpr int XPL = RH * RW + 1;
-    __shared__ float Gs[32 * GPL];
+    // output channels per block = CF_WG_RB 32-row MFMA blocks per wave (2 measured slower: 57 against 67 TFLOP/s on
+    // 64 -> 256 @128x128 -- 160 accumulator registers on top of the staging registers; 2-row pixel tiles, CF_WG_TH = 2,
+    // for twice the blocks per CU: 63)
+    constexpr int NRB = CF_WG_RB, NCO = 32 * NRB;
+    __shared__ float Gs[NCO * GPL];
     __shared__ float Xs[32 * XPL];
     const int tid = threadIdx.x, lane = tid & 63;
     const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's kernel row
     const int c = lane & 31, kk = lane >> 5;
-    const int split = blockIdx.x, co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
+    // Block order: the (co, ci) groups of one pixel split read the same dY / X tiles, so they should run at the same time
+    // on the same XCD (each XCD has its own L2; consecutive workgroup ids go round the 8 XCDs).  id = 8 * (G * q + group)
+    // + xcd with split = 8 q + xcd: the G blocks of a split follow each other on one XCD and the tiles are fetched from
+    // HBM about once instead of once per group (measured 49 -> see DESIGN.md TFLOP/s on 64->256 @128x128).
+    const int gco = (Cout + NCO - 1) / NCO, G = gco * ((Cin + 31) / 32);
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int group = j % G, split = (j / G) * 8 + xcd;
+    if (split >= nsplit) return;     // workgroup-uniform: the grid is padded to whole rounds of 8 splits
+    const int co0 = (group % gco) * NCO, ci0 = (group / gco) * 32;
     const long long plane = (long long)H * W;
-    cf_f32x16 acc[KS];
+    cf_f32x16 acc[NRB][KS];
 #pragma unroll
-    for (int tx = 0; tx < KS; ++tx)
+    for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[tx][i] = 0.f;
+        for (int tx = 0; tx < KS; ++tx)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][tx][i] = 0.f;
     const int t0 = (int)((long long)split * ntiles / nsplit), t1 = (int)((long long)(split + 1) * ntiles / nsplit);
+    auto compute = [&]() {
+        // pixel pair s = (row r, columns 2q, 2q+1); lane (c, kk): A = dY[co = c][pixel 2s + kk], B = X[ci = c][same pixel + tap]
+#pragma unroll 2
+        for (int s = 0; s < CF_WG_TH * CF_TW / 2; ++s) {
+            const int p = 2 * s + kk, r = p / CF_TW, col = p % CF_TW;
+            float a[NRB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) a[rb] = Gs[(32 * rb + c) * GPL + p];
+            const float* xb = Xs + c * XPL + (r + ty) * RW + col;
+#pragma unroll
+            for (int tx = 0; tx < KS; ++tx) {
+                const float b = xb[tx];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc[rb][tx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb], b, acc[rb][tx], 0, 0, 0);
+            }
+        }
+    };
+    // Fast staging (even window start, W % 4 == 0, aligned bases): the tile's dY quads and X pairs are requested as
+    // straight-line vector loads from clamped addresses into registers -- all in flight together, and for tile t+1 while
+    // tile t is in the matrix cores -- and zeroed afterwards where they lie outside the tensor.  (Element-wise guarded
+    // loads in a loop cost one memory round trip each: the kernel then spends its time staging, 49 TFLOP/s.)
+    const bool fast = (P % 2 == 0) && (W % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+    if (fast) {
+        constexpr int NQG = NCO * CF_WG_TH * CF_TW / 4, NG = (NQG + THREADS - 1) / THREADS;
+        constexpr int XW2 = RW / 2, NQX = 32 * RH * XW2, NX = (NQX + THREADS - 1) / THREADS;
+        float4 g[NG];
+        float2 xv[NX];
+        auto load_tile = [&](int t) {
+            const int n = t / (tiles_x * tiles_y), rem = t - n * (tiles_x * tiles_y);
+            const int h0 = (rem / tiles_x) * CF_WG_TH, w0 = (rem % tiles_x) * CF_TW;
+#pragma unroll
+            for (int it = 0; it < NG; ++it) {
+                const int q0 = tid + it * THREADS, q = q0 < NQG ? q0 : NQG - 1;
+                const int co = q / (CF_WG_TH * CF_TW / 4), pq = q - co * (CF_WG_TH * CF_TW / 4);
+                const int gh = h0 + pq / (CF_TW / 4), gw = w0 + 4 * (pq % (CF_TW / 4));
+                const int coc = co0 + co < Cout ? co0 + co : Cout - 1, ghc = gh < H ? gh : H - 1, gwc = gw + 4 <= W ? gw : W - 4;
+                const float4 v = *reinterpret_cast<const float4*>(dy + ((long long)n * Cout + coc) * plane + (long long)ghc * W + gwc);
+                const bool ok = co0 + co < Cout && gh < H && gw < W;
+                g[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int it = 0; it < NX; ++it) {
+                const int q0 = tid + it * THREADS, q = q0 < NQX ? q0 : NQX - 1;
+                const int ci = q / (RH * XW2), r2 = q - ci * (RH * XW2);
+                const int r = r2 / XW2, c2 = r2 - r * XW2;
+                const int gh = h0 - P + r, gw = w0 - P + 2 * c2;
+                const int cic = ci0 + ci < Cin ? ci0 + ci : Cin - 1;
+                const int ghc = gh < 0 ? 0 : (gh < H ? gh : H - 1), gwc = gw < 0 ? 0 : (gw + 2 <= W ? gw : W - 2);
+                const float2 v = *reinterpret_cast<const float2*>(x + ((long long)n * Cin + cic) * plane + (long long)ghc * W + gwc);
+                const bool ok = ci0 + ci < Cin && gh >= 0 && gh < H && gw >= 0 && gw < W;
+                xv[it] = ok ? v : make_float2(0.f, 0.f);
+            }
+        };
+        auto store_tile = [&]() {
+#pragma unroll
+            for (int it = 0; it < NG; ++it) {
+                const int q = tid + it * THREADS;
+                if (q < NQG) {
+                    const int co = q / (CF_WG_TH * CF_TW / 4), pq = q - co * (CF_WG_TH * CF_TW / 4);
+                    float* d = Gs + co * GPL + 4 * pq;
+                    d[0] = g[it].x; d[1] = g[it].y; d[2] = g[it].z; d[3] = g[it].w;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NX; ++it) {
+                const int q = tid + it * THREADS;
+                if (q < NQX) {
+                    const int ci = q / (RH * XW2), r2 = q - ci * (RH * XW2);
+                    float* d = Xs + ci * XPL + 2 * r2;     // r * RW + 2 c2 = 2 (r * XW2 + c2)
+                    d[0] = xv[it].x; d[1] = xv[it].y;
+                }
+            }
+        };
+        if (t0 < t1) load_tile(t0);
+        for (int t = t0; t < t1; ++t) {
+            __syncthreads();
+            store_tile();
+            __syncthreads();
+            if (t + 1 < t1) load_tile(t + 1);
+            compute();
+        }
+    } else {
     for (int t = t0; t < t1; ++t) {
         const int n = t / (tiles_x * tiles_y), rem = t - n * (tiles_x * tiles_y);
-        const int h0 = (rem / tiles_x) * CF_TH, w0 = (rem % tiles_x) * CF_TW;
+        const int h0 = (rem / tiles_x) * CF_WG_TH, w0 = (rem % tiles_x) * CF_TW;
         __syncthreads();
-        for (int e = tid; e < 32 * CF_TH * CF_TW; e += THREADS) {
-            const int co = e / (CF_TH * CF_TW), p = e - co * (CF_TH * CF_TW);
+        for (int e = tid; e < NCO * CF_WG_TH * CF_TW; e += THREADS) {
+            const int co = e / (CF_WG_TH * CF_TW), p = e - co * (CF_WG_TH * CF_TW);
             const int gh = h0 + p / CF_TW, gw = w0 + p % CF_TW;
             float v = 0.f;
             if (co0 + co < Cout && gh < H && gw < W) v = dy[((long long)n * Cout + co0 + co) * plane + (long long)gh * W + gw];
@@ -156,27 +255,22 @@ __global__ void __launch_bounds__(64 * KS) conv_f32_wgrad_kernel(const float* __
             Xs[ci * XPL + r * RW + col] = v;
         }
         __syncthreads();
-        // pixel pair s = (row r, columns 2q, 2q+1); lane (c, kk): A = dY[co = c][pixel 2s + kk], B = X[ci = c][same pixel + tap]
-#pragma unroll 2
-        for (int s = 0; s < CF_TH * CF_TW / 2; ++s) {
-            const int p = 2 * s + kk, r = p / CF_TW, col = p % CF_TW;
-            const float a = Gs[c * GPL + p];
-            const float* xb = Xs + c * XPL + (r + ty) * RW + col;
-#pragma unroll
-            for (int tx = 0; tx < KS; ++tx) acc[tx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[tx], acc[tx], 0, 0, 0);
-        }
+        compute();
+    }
     }
     // D[row = co][col = ci]
     float* dst = part + (long long)split * Cout * Cin * KS * KS;
     const int ci = ci0 + c;
     if (ci < Cin) {
 #pragma unroll
-        for (int tx = 0; tx < KS; ++tx)
+        for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int co = co0 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
-                if (co < Cout) dst[(((long long)co * Cin + ci) * KS + ty) * KS + tx] = acc[tx][reg];
-            }
+            for (int tx = 0; tx < KS; ++tx)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int co = co0 + 32 * rb + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+                    if (co < Cout) dst[(((long long)co * Cin + ci) * KS + ty) * KS + tx] = acc[rb][tx][reg];
+                }
     }
 }
 
@@ -191,8 +285,8 @@ __global__ void __launch_bounds__(256) conv_f32_wgrad_reduce_kernel(const float*
 
 static int cf_mpad(int64_t M) { return (int)(cdiv(M, CF_MB) * CF_MB); }
 static int cf_nsplit(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W) {
-    const int64_t ntiles = N * cdiv(H, CF_TH) * cdiv(W, CF_TW);
-    const int64_t groups = cdiv(Cout, 32) * cdiv(Cin, 32);
+    const int64_t ntiles = N * cdiv(H, CF_WG_TH) * cdiv(W, CF_TW);
+    const int64_t groups = cdiv(Cout, 32 * CF_WG_RB) * cdiv(Cin, 32);
     int64_t want = 1024 / (groups > 0 ? groups : 1);   // ~4 blocks per CU
     if (want > ntiles) want = ntiles;
     if (want < 1) want = 1;
@@ -265,10 +359,12 @@ OFASR_EXPORT int ofasr_conv2d_f32_wgrad(const void* dy, const void* x, float* dw
     OFASR_REQUIRE(workspace && workspace_bytes >= need, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", name,
                   workspace_bytes, need);
     const int nsplit = cf_nsplit(N, Cin, Cout, H, W);
-    const int tiles_x = (int)cdiv(W, CF_TW), tiles_y = (int)cdiv(H, CF_TH);
+    const int tiles_x = (int)cdiv(W, CF_TW), tiles_y = (int)cdiv(H, CF_WG_TH);
     const int ntiles = (int)(N * tiles_x * tiles_y);
     hipStream_t st = as_stream(stream);
-    dim3 grid((unsigned)nsplit, (unsigned)cdiv(Cout, 32), (unsigned)cdiv(Cin, 32));
+    const long long nblocks = cdiv(nsplit, 8) * 8 * cdiv(Cout, 32 * CF_WG_RB) * cdiv(Cin, 32);
+    OFASR_REQUIRE(nblocks <= INT32_MAX, OFASR_ERR_UNSUPPORTED, "%s: too many blocks", name);
+    dim3 grid((unsigned)nblocks);
     prof_note(4.0 * (double)N * (double)H * (double)W * (double)(Cin + Cout),
               2.0 * (double)N * (double)H * (double)W * (double)Cin * (double)Cout * K * K);
     if (K == 5)

@@ -9,12 +9,15 @@
 // Python side makes 1 FFI call per direction instead of ~25 (each with its own autograd node, allocations
 // and ctypes marshalling), which is what bounded the training step once the kernels were fast.
 #include "ofasr_common.h"
+
+#include <atomic>
 #include <mutex>
 #include <vector>
 
 namespace ofasr {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static std::atomic<int> g_bn_bwd_stat{[] { const char* e = getenv("OFASR_MBCONV_BN_BWD_STAT"); return (e && e[0] == '1') ? 1 : 0; }()};
 
 struct MbSizes {
     size_t es;            // activation element size
@@ -497,9 +500,12 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
                      (reinterpret_cast<uintptr_t>(tC) & 15) == 0 &&
                      pwconv_dgrad_bx_supported(tB, y1, dx, d->residual ? dout : nullptr, d->w1, d->ldw1, d->Cin, d->mid, HW,
                                                d->dtype);
-    // ... and without the reduction pass where the producer of da can take the sums itself (BwdStatOut;
-    // OFASR_MBCONV_BN_BWD_STAT=0 restores the pass): the project input gradient for BN2
-    static const bool bn_stat = [] { const char* e = getenv("OFASR_MBCONV_BN_BWD_STAT"); return !(e && e[0] == '0'); }();
+    // ... and, optionally, without the reduction pass where the producer of da can take the sums itself (BwdStatOut): the
+    // project input gradient for BN2.  OFF by default (OFASR_MBCONV_BN_BWD_STAT=1 / ofasr_debug_mbconv_bn_bwd_stat(1)
+    // enable it): alone the pair costs 38.9 + 9.1 us against 25.0 + 24.3 + 5.5 us (rocprofv3, N=16 64x64 mid 384), but
+    // the training step is 1 % SLOWER with it (7.01 against 6.94 ms, three A/B pairs on one box) -- the longer
+    // store-bound kernel shares HBM with the side stream's weight-gradient kernels for longer.
+    const bool bn_stat = g_bn_bwd_stat.load(std::memory_order_relaxed) != 0;
     const int P2b = pwconv_stat_units(d->N, d->Cout, HW);
     const bool st2 = bxp && bn_stat && pwconv_dgrad_bstat_supported(t3, y2, tA, d->w2, d->ldw2, d->mid, d->Cout, HW, d->dtype) &&
                      (size_t)P2b * (size_t)d->mid * sizeof(float2) <= s.stat_a;
@@ -599,6 +605,10 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
         }
     }
     return rc;
+}
+
+OFASR_EXPORT int ofasr_debug_mbconv_bn_bwd_stat(int enable) {
+    return g_bn_bwd_stat.exchange(enable ? 1 : 0, std::memory_order_relaxed);
 }
 
 OFASR_EXPORT int ofasr_mbconv_defer_join(int enable) {

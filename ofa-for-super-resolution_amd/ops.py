@@ -751,9 +751,23 @@ def _conv_hip_ok(x, weight, stride, padding, dilation, groups):
             and groups == 1 and padding == (k // 2, k // 2))
 
 
+def _conv_f32_policy(cin, cout, k, H, W):
+    """(forward, input gradient, weight gradient) on the own fp32 kernels -- measured on MI355X at the S4 shapes
+    (tools/kbench.py --dtype f32, profiles/r02_kbench_f32.txt): the wide convs' forward / input gradient run at the
+    vendor kernels' rate (120 against 122 TFLOP/s on 64 -> 256 @128x128, 76 % of the fp32 matrix peak); the weight
+    gradient (67 against 119) and the 3-channel stem / head convs (a 32-row matrix tile for 3 channels) are slower, so
+    those stay on the vendor library for the regular training shapes.  Ragged sizes (Set14 evaluation) always run the
+    own kernels: the vendor's per-shape kernel search costs more than the convolution."""
+    if CONV_FORCE_HIP or W % 8 != 0 or H % 2 != 0:
+        return True, True, True
+    wide = min(cin, cout) >= 16
+    return wide, wide, False
+
+
 class Conv2dF32Fn(Function):
     """nn.Conv2d of the static ConvLayer with fp32 activations: forward, input and weight gradients on the fp32 matrix
-    instruction (csrc/conv2d_f32.hip) -- the reference's arithmetic, any H / W."""
+    instruction (csrc/conv2d_f32.hip) -- the reference's arithmetic, any H / W -- or, per _conv_f32_policy, the vendor
+    convolution where that is measured faster."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -761,13 +775,16 @@ class Conv2dF32Fn(Function):
         weight = weight.contiguous()
         N, Cin, H, W = x.shape
         Cout, _, K, _ = weight.shape
+        ctx.policy = _conv_f32_policy(Cin, Cout, K, H, W)
+        ctx.save_for_backward(x, weight)
+        if not ctx.policy[0]:
+            return torch.nn.functional.conv2d(x, weight, padding=K // 2)
         L = _C.lib()
         y = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device)
         wst, wsp, wsn = _ws(L.ofasr_conv2d_f32_workspace(Cin, Cout, K, 0), x.device)
         with _timed("conv2d_f32_fwd_%dto%d_k%d" % (Cin, Cout, K), (x.numel() + y.numel()) * 4, 2 * N * H * W * Cin * Cout * K * K):
             _C.check(L.ofasr_conv2d_f32_fwd(_p(x), _p(weight), _p(y), N, Cin, Cout, H, W, K, wsp, wsn, _stream()),
                      "conv2d_f32_fwd")
-        ctx.save_for_backward(x, weight)
         return y
 
     @staticmethod
@@ -779,12 +796,22 @@ class Conv2dF32Fn(Function):
         dy = dy.contiguous()
         L = _C.lib()
         dx = dw = None
-        if ctx.needs_input_grad[1]:
+        _, dgrad_own, wgrad_own = ctx.policy
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if (need_dx and not dgrad_own) or (need_dw and not wgrad_own):
+            vdx, vdw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [K // 2, K // 2], [1, 1], False,
+                                                              [0, 0], 1, [need_dx and not dgrad_own,
+                                                                          need_dw and not wgrad_own, False])
+            if need_dx and not dgrad_own:
+                dx, need_dx = vdx, False
+            if need_dw and not wgrad_own:
+                dw, need_dw = vdw, False
+        if need_dw:
             dw = torch.empty_like(weight)
             wst2, wsp2, wsn2 = _ws(L.ofasr_conv2d_f32_wgrad_workspace(N, Cin, Cout, H, W, K), x.device)
             _C.check(L.ofasr_conv2d_f32_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Cout, H, W, K, wsp2, wsn2, _stream()),
                      "conv2d_f32_wgrad")
-        if ctx.needs_input_grad[0]:
+        if need_dx:
             dx = torch.empty_like(x)
             wst, wsp, wsn = _ws(L.ofasr_conv2d_f32_workspace(Cin, Cout, K, 1), x.device)
             _C.check(L.ofasr_conv2d_f32_dgrad(_p(dy), _p(weight), _p(dx), N, Cin, Cout, H, W, K, wsp, wsn, _stream()),

@@ -97,10 +97,14 @@ CASES = [
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "N%d_%dx%d_e%d_k%d_%s_%s" % (
     c[0], c[1], c[2], c[3], c[4], "train" if c[5] else "eval", "bf16" if c[6] == torch.bfloat16 else "f16"))
-def test_composite_block_16bit_vs_oracle(ora, case):
+@pytest.mark.parametrize("bstat", [False, True], ids=["", "bn2sums_in_dgrad"])
+def test_composite_block_16bit_vs_oracle(ora, case, bstat):
     from oracle import composite16 as c16
     N, Hh, Ww, e, K, train, dtype = case
     ops, C = amd("ops"), amd("_C")
+    if bstat and not (train and (Hh * Ww) % 128 == 0 and 64 * e in (256, 384)):
+        pytest.skip("the BN2-sums-in-the-project-dgrad variant (off by default) only exists for the slab-walk kernel")
+    was_bstat = C.lib().ofasr_debug_mbconv_bn_bwd_stat(1 if bstat else 0)
     block, layer = _make_block(100 * K + e)
     block.to(DEV).train(train)
     layer.active_kernel_size, layer.active_expand_ratio = K, e
@@ -130,6 +134,7 @@ def test_composite_block_16bit_vs_oracle(ora, case):
         ops.SHARED_TMP = was_tmp
         ops.deferred_weight_grads(was_defer)
         ops._TMP_CACHE.clear()
+        C.lib().ofasr_debug_mbconv_bn_bwd_stat(was_bstat)
 
     # ---- routing: the kernel variants bench.py's timed step runs (profiles/r02_*_steps.txt) served this call
     T = TNAME[dtype]
@@ -141,9 +146,12 @@ def test_composite_block_16bit_vs_oracle(ora, case):
     if train and aligned:
         if mid in (256, 384):
             assert ran(fwd_table, "pw_fanout_slabs_kernel<%s, %d, 1>" % (T, mid // 128)) == 1, fwd_table   # + BN1 stats
-            # project dgrad + the BN2-backward sums of what it writes (BwdStatOut): no reduction pass for BN2
-            assert ran(bwd_table, "pw_fanout_slabs_kernel<%s, %d, 2>" % (T, mid // 128)) == 1, bwd_table
-            assert ran(bwd_table, "bn_bwd_coef_cp_kernel") == 1, bwd_table
+            if bstat:   # project dgrad + the BN2-backward sums of what it writes (BwdStatOut): no reduction pass for BN2
+                assert ran(bwd_table, "pw_fanout_slabs_kernel<%s, %d, 2>" % (T, mid // 128)) == 1, bwd_table
+                assert ran(bwd_table, "bn_bwd_coef_cp_kernel") == 1, bwd_table
+            else:
+                assert ran(bwd_table, "pw_fanout_slabs_kernel<%s, %d, 0>" % (T, mid // 128)) == 1, bwd_table
+                assert ran(bwd_table, "bn_bwd_coef_cp_kernel") == 0, bwd_table
         assert ran(fwd_table, "pw_fanin_pipe_kernel<%s, true, true, false>" % T) == 1, fwd_table      # project: XF + fold
         # backward: BN1 / BN2 have no apply pass -- their consumers read (da, y) through the BN backward (BwdXf variants)
         assert ran(bwd_table, "pw_fanin_pipe_kernel<%s, false, true, true>" % T) == 1, bwd_table   # expand dgrad (+dout)

@@ -143,7 +143,11 @@ def test_conv2d_fp32_vs_oracle(ora, case):
     conv.weight.data.copy_(torch.from_numpy(w))
     xt = torch.from_numpy(x).to(DEV).requires_grad_(True)
     C.reset_launch_counts()
-    y = ops.conv2d(xt, conv)
+    was, ops.CONV_FORCE_HIP = ops.CONV_FORCE_HIP, True   # the own kernels whatever the measured policy says for the shape
+    try:
+        y = ops.conv2d(xt, conv)
+    finally:
+        ops.CONV_FORCE_HIP = was
     assert C.launch_count("conv_f32_kernel") == 1 and y.dtype == torch.float32
     y_ref = ora.conv2d_fwd(x, w)
     assert_close(y.detach().cpu().numpy(), y_ref, 5e-5, 5e-6, "y")
@@ -226,3 +230,28 @@ def test_conv_layer_inference_one_kernel_vs_oracle(ora, case, dtype):
     assert C.launch_count("conv_prep_kernel") == 1
     if not use_bn and act is None:
         assert_close(y3.float().cpu().numpy(), 2.0 * ref.astype(np.float32), rt, 2 * rt, "y after the weight update")
+
+
+def test_conv2d_fp32_policy_routes_and_matches_oracle(ora):
+    """_conv_f32_policy: a regular training shape takes the own forward / input gradient and the vendor weight gradient;
+    a 3-channel conv the vendor kernels; a ragged width the own kernels for all three -- same results either way."""
+    ops, C = amd("ops"), amd("_C")
+    for case, want in (((2, 64, 128, 8, 64, 5), (1, 1, 0)), ((1, 64, 3, 8, 64, 5), (0, 0, 0)), ((1, 64, 128, 8, 60, 5), (1, 1, 1))):
+        N, Cin, Cout, H, W, K = case
+        x = det_uniform((N, Cin, H, W), "cvp/x%s" % (case,))
+        a = float(np.sqrt(3.0 / (Cin * K * K)))
+        w = det_uniform((Cout, Cin, K, K), "cvp/w%s" % (case,), -a, a)
+        dy = det_uniform((N, Cout, H, W), "cvp/dy%s" % (case,))
+        conv = torch.nn.Conv2d(Cin, Cout, K, padding=K // 2, bias=False).to(DEV)
+        conv.weight.data.copy_(torch.from_numpy(w))
+        xt = torch.from_numpy(x).to(DEV).requires_grad_(True)
+        C.reset_launch_counts()
+        y = ops.conv2d(xt, conv)
+        y.backward(torch.from_numpy(dy).to(DEV))
+        assert C.launch_count("conv_f32_kernel") == want[0] + want[1], (case, C.launch_table())
+        assert C.launch_count("conv_f32_wgrad_kernel") == want[2], (case, C.launch_table())
+        dx_ref, dw_ref = ora.conv2d_bwd(dy, x, w)
+        assert_close(y.detach().cpu().numpy(), ora.conv2d_fwd(x, w), 5e-5, 5e-6, "y")
+        scale = float(np.sqrt(Cout * K * K / max(Cin * K * K, 1)))
+        assert_close(xt.grad.cpu().numpy(), dx_ref, 5e-5, 5e-6 * max(1.0, scale), "dx")
+        assert_close(conv.weight.grad.cpu().numpy(), dw_ref, 1e-4, 2e-6 * float(np.abs(dw_ref).max()) * np.sqrt(N * H * W), "dw")

@@ -108,6 +108,35 @@ def main():
                             yc, xc, w16, None, [1, 1], [K // 2, K // 2], [1, 1], False, [0, 0], 1, [False, True, False]), 0)[1])):
             cases.append((nm, nb, fn))
             flops[nm] = fl
+    if a.dtype == "f32":   # fp32 static convs: own kernels on v_mfma_f32_32x32x2_f32 against the vendor's
+        for (ci, co, hh, K) in ((3, 64, S, 5), (64, 256, S, 5), (64, 256, 2 * S, 5), (64, 3, 4 * S, 5)):
+            xc = torch.randn(N, ci, hh, hh, device=dev)
+            yc = torch.randn(N, co, hh, hh, device=dev)
+            wc = torch.randn(co, ci, K, K, device=dev) * 0.05
+            nb = (xc.numel() + yc.numel()) * 4
+            fl = 2.0 * N * hh * hh * ci * co * K * K
+            wsf = torch.empty(max(L.ofasr_conv2d_f32_workspace(ci, co, K, 0), L.ofasr_conv2d_f32_workspace(ci, co, K, 1),
+                                  L.ofasr_conv2d_f32_wgrad_workspace(N, ci, co, hh, hh, K), 16), dtype=torch.uint8, device=dev)
+            wn = wsf.numel()
+            for nm, fn in (("conv2d_f32_fwd %d->%d k%d @%d" % (ci, co, K, hh),
+                            lambda xc=xc, yc=yc, wc=wc, ci=ci, co=co, hh=hh, K=K, wsf=wsf, wn=wn: L.ofasr_conv2d_f32_fwd(
+                                P(xc), P(wc), P(yc), N, ci, co, hh, hh, K, P(wsf), wn, st)),
+                           ("conv2d_f32_dgrad %d<-%d k%d @%d" % (ci, co, K, hh),
+                            lambda xc=xc, yc=yc, wc=wc, ci=ci, co=co, hh=hh, K=K, wsf=wsf, wn=wn: L.ofasr_conv2d_f32_dgrad(
+                                P(yc), P(wc), P(xc), N, ci, co, hh, hh, K, P(wsf), wn, st)),
+                           ("conv2d_f32_wgrad %d->%d k%d @%d" % (ci, co, K, hh),
+                            lambda xc=xc, yc=yc, wc=wc, ci=ci, co=co, hh=hh, K=K, wsf=wsf, wn=wn: L.ofasr_conv2d_f32_wgrad(
+                                P(yc), P(xc), P(wc), N, ci, co, hh, hh, K, P(wsf), wn, st)),
+                           ("miopen32 fwd %d->%d k%d @%d" % (ci, co, K, hh),
+                            lambda xc=xc, wc=wc, K=K: (F.conv2d(xc, wc, padding=K // 2), 0)[1]),
+                           ("miopen32 bwd(dx) %d->%d k%d @%d" % (ci, co, K, hh),
+                            lambda xc=xc, yc=yc, wc=wc, K=K: (torch.ops.aten.convolution_backward(
+                                yc, xc, wc, None, [1, 1], [K // 2, K // 2], [1, 1], False, [0, 0], 1, [True, False, False]), 0)[1]),
+                           ("miopen32 bwd(dw) %d->%d k%d @%d" % (ci, co, K, hh),
+                            lambda xc=xc, yc=yc, wc=wc, K=K: (torch.ops.aten.convolution_backward(
+                                yc, xc, wc, None, [1, 1], [K // 2, K // 2], [1, 1], False, [0, 0], 1, [False, True, False]), 0)[1])):
+                cases.append((nm, nb, fn))
+                flops[nm] = fl
     torch.backends.cudnn.benchmark = True
     for name, nbytes, fn in cases:
         if a.only and a.only not in name:
