@@ -224,8 +224,10 @@ def roofline_from(summ, nprof, dtype):
         return None, table, None
     name, top = max(cands.items(), key=lambda kv: kv[1]["total_us"])
     secs = top["total_us"] * 1e-6
-    mfma_bound = name.startswith("conv_igemm") or name.startswith("conv_wgrad_kernel")
     peak_tf = MFMA_PEAK_TF[dtype]
+    # which roof bounds the kernel: its algorithmic intensity against the ridge (peak flops / peak bytes); the one-kernel
+    # MB block (9.3 GFLOP over 25 MB at N=16: 370 flop/B, ridge 312) and the static convs sit on the matrix side
+    mfma_bound = top["flops"] > 0 and top["flops"] / top["bytes"] > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
     traffic, source = pmc_traffic(name)
     if mfma_bound:
         ach = top["flops"] / secs / 1e12
