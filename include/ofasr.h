@@ -270,6 +270,22 @@ int ofasr_mbconv_infer(const ofasr_mbconv_desc* d, const void* x, void* out, voi
  * ragged widths on the right, which is the convolution's own padding, and drops the extra output columns).
  * ------------------------------------------------------------------------------------------- */
 size_t ofasr_conv2d_workspace(int64_t Cin, int64_t Cout, int K, int dgrad);
+/* Training form of ConvLayer's conv -> BatchNorm: the forward also leaves the BatchNorm statistics partials of what it
+ * stores ([Cout][units] (sum, sum of squares) in fp32, units = ofasr_conv2d_stat_units(...)), so no pass reads the conv
+ * output just for statistics; fold them with ofasr_bn_fwd_cp (apply in the same call) or ofasr_bn_finalize_cp
+ * (+ ofasr_pixel_shuffle2_bn for the decoder stages: BN apply and PixelShuffle(2) in one pass). */
+int ofasr_conv2d_stat_units(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K);
+int ofasr_conv2d_fwd_stat(const void* x, const float* w, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
+                          int64_t W, int K, int dtype, void* partial, int64_t units, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int ofasr_bn_fwd_cp(const void* x, const void* residual, void* y, const void* partial, int64_t P, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, double momentum, double eps, int training,
+                    float* stats, int64_t N, int64_t C, int64_t HW, int act, int dtype, void* stream);
+int ofasr_bn_finalize_cp(const void* partial, int64_t P, int64_t C, double count, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, double momentum, double eps, int training, float* stats,
+                         void* stream);
+int ofasr_pixel_shuffle2_bn(const void* x, void* y, const float* stats, int64_t N, int64_t C, int64_t H, int64_t W,
+                            int dtype, void* stream);
 /* Inference form of a whole ConvLayer (reference ofa/layers.py:120-151 in eval mode; the decoder's conv -> BN ->
  * PixelShuffle(2) stages, ofa_mbs4.py:111-123): y = act(BN_eval(conv(x))) as ONE kernel -- the BatchNorm's affine map
  * (scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale) is applied to the fp32 accumulators

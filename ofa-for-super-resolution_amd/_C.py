@@ -61,6 +61,14 @@ SIGNATURES = {
     "ofasr_bn_act_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                   _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
     "ofasr_conv2d_workspace": (_c_sz, [_c_i64, _c_i64, _c_int, _c_int]),
+    "ofasr_conv2d_stat_units": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int]),
+    "ofasr_conv2d_fwd_stat": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp,
+                                       _c_i64, _c_vp, _c_sz, _c_vp]),
+    "ofasr_bn_fwd_cp": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_double,
+                                 ctypes.c_double, _c_int, _c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp]),
+    "ofasr_bn_finalize_cp": (_c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_double,
+                                      ctypes.c_double, _c_int, _c_vp, _c_vp]),
+    "ofasr_pixel_shuffle2_bn": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_vp]),
     "ofasr_conv2d_infer_operand_bytes": (_c_sz, [_c_i64, _c_i64, _c_int]),
     "ofasr_conv2d_infer_prepare": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_double, _c_i64, _c_i64, _c_int, _c_int,
                                             _c_vp, _c_sz, _c_vp]),

@@ -775,6 +775,29 @@ OFASR_EXPORT int ofasr_bn_fwd(const void* x, const void* residual, void* y, cons
     return launch_bn_apply(name, x, residual, y, src, N, C, HW, act, dtype, stream);
 }
 
+// BatchNorm forward whose batch statistics come from the producing conv's epilogue partials ([C][P] (sum, sum of squares),
+// e.g. ofasr_conv2d_fwd_stat): no pass over x for statistics.
+//   ofasr_bn_fwd_cp       apply (+act, +residual) with the fold of the partials in every block of the apply kernel; stats
+//                         [4*C] receives mean | invstd | scale | shift, running statistics are updated (training)
+//   ofasr_bn_finalize_cp  only the fold: stats + running statistics (the apply is done by another kernel, e.g.
+//                         ofasr_pixel_shuffle2_bn)
+OFASR_EXPORT int ofasr_bn_fwd_cp(const void* x, const void* residual, void* y, const void* partial, int64_t P,
+                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 double momentum, double eps, int training, float* stats, int64_t N, int64_t C, int64_t HW,
+                                 int act, int dtype, void* stream) {
+    OFASR_REQUIRE(act == 0 || act == 1, OFASR_ERR_UNSUPPORTED, "ofasr_bn_fwd_cp: act %d not in {0 none, 1 relu6}", act);
+    return bn_fwd_cp(x, residual, y, (const float2*)partial, P, gamma, beta, running_mean, running_var, momentum, eps, training,
+                     stats, N, C, HW, act, dtype, stream);
+}
+
+OFASR_EXPORT int ofasr_bn_finalize_cp(const void* partial, int64_t P, int64_t C, double count, const float* gamma,
+                                      const float* beta, float* running_mean, float* running_var, double momentum, double eps,
+                                      int training, float* stats, void* stream) {
+    OFASR_REQUIRE(stats != nullptr && C > 0, OFASR_ERR_INVALID_ARG, "ofasr_bn_finalize_cp: null stats");
+    return bn_finalize_cp((const float2*)partial, P, C, count, gamma, beta, running_mean, running_var, momentum, eps, training,
+                          stats, stats + C, stats + 2 * C, stats + 3 * C, nullptr, nullptr, nullptr, stream);
+}
+
 OFASR_EXPORT int ofasr_bn_act_bwd(const void* dy, const void* x, const void* residual, void* dx, void* dresidual,
                                   const float* scale, const float* shift, const float* mean, const float* invstd,
                                   float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t HW, int act, int training,

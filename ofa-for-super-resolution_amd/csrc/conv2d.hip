@@ -110,6 +110,8 @@ __device__ __forceinline__ void cv_lds_barrier() { asm volatile("s_waitcnt lgkmc
 struct CvEpi {
     const float* ss;
     int act;
+    float2* stat;   // training: per-channel (sum, sum of squares) of what each wave stores -> stat[m * P + unit], or nullptr
+    int P;          //   unit = ((n * tiles + tile) * WP + wp): one per wave's 2 x 64 pixel strip
 };
 
 template <typename T, int KS, int RB, int WM, int WP, bool ONEK>
@@ -289,7 +291,8 @@ __global__ void __launch_bounds__(64 * WM * WP, 2) conv_igemm_kernel(const T* __
         }
         return;
     }
-    if (oy < H && ox < W) {
+    const bool inside = oy < H && ox < W;
+    if (inside) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
@@ -301,6 +304,32 @@ __global__ void __launch_bounds__(64 * WM * WP, 2) conv_igemm_kernel(const T* __
                                                                 pack2<T>(acc[rb][2][reg], acc[rb][3][reg]));
                 }
             }
+        }
+    }
+    if (epi.stat != nullptr) {
+        // BatchNorm statistics of the values as stored (ofa/layers.py:120-151: the BN that follows the conv): the 32 lanes
+        // of a half-wave hold 128 pixels of the same 16 channels per row block -> reduce-scatter, one partial per
+        // (channel, wave strip); pixels outside the image count as zero
+        const int unit = (n * (int)gridDim.x + tile) * WP + wp;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            float sv[16], qv[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                float ss = 0.f, qq = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float v = inside ? to_float(from_float<T>(acc[rb][t][reg])) : 0.f;
+                    ss += v;
+                    qq = fmaf(v, v, qq);
+                }
+                sv[reg] = ss;
+                qv[reg] = qq;
+            }
+            half_wave_row_sums(sv, qv, c);
+            const int rho = half_wave_row_reg(c);
+            const int m = (grb0 + rb) * 32 + (rho & 3) + 8 * (rho >> 2) + 4 * h;
+            if ((c & 1) == 0 && m < M) epi.stat[(long long)m * epi.P + unit] = make_float2(sv[0], qv[0]);
         }
     }
 }
@@ -373,10 +402,10 @@ static int launch_conv_run(const char* name, const void* x, const void* ws, void
 
 template <typename T>
 static int launch_conv2d(const char* name, const void* x, const float* w, void* y, int64_t N, int64_t Cin, int64_t Cout,
-                         int64_t H, int64_t W, int K, int dgrad, void* ws, hipStream_t st) {
+                         int64_t H, int64_t W, int K, int dgrad, void* ws, hipStream_t st, StatOut so = StatOut{nullptr, 0}) {
     int rc = launch_conv_prep<T>(name, w, Cin, Cout, K, dgrad, ws, CvBn{}, st);
     if (rc) return rc;
-    return launch_conv_run<T>(name, x, ws, y, N, Cin, Cout, H, W, K, dgrad, CvEpi{nullptr, 0}, st);
+    return launch_conv_run<T>(name, x, ws, y, N, Cin, Cout, H, W, K, dgrad, CvEpi{nullptr, 0, so.partial, so.P}, st);
 }
 
 // ================================================================================= weight gradient
@@ -669,8 +698,15 @@ static int launch_conv2d_wgrad(const char* name, const void* dy, const void* x, 
     return check_launch(name);
 }
 
+static int conv_stat_units(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K) {
+    const CvPlan p = cv_plan(Cin, Cout, K, 0, N, H, W);
+    const int wp = p.th / 2;     // waves along the pixel rows of a tile: 2 rows each
+    return (int)(N * cdiv(W, CV_TW) * cdiv(H, p.th) * wp);
+}
+
 static int conv2d_entry(const char* name, const void* x, const float* w, void* y, int64_t N, int64_t Cin, int64_t Cout,
-                        int64_t H, int64_t W, int K, int dtype, int dgrad, void* ws, size_t ws_bytes, void* stream) {
+                        int64_t H, int64_t W, int K, int dtype, int dgrad, void* ws, size_t ws_bytes, void* stream,
+                        StatOut so = StatOut{nullptr, 0}) {
     OFASR_REQUIRE(x && w && y, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
     OFASR_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, OFASR_ERR_INVALID_ARG, "%s: bad shape", name);
     OFASR_REQUIRE(dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_UNSUPPORTED,
@@ -683,8 +719,11 @@ static int conv2d_entry(const char* name, const void* x, const float* w, void* y
     OFASR_REQUIRE(ws && ws_bytes >= p.img_bytes, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", name,
                   ws_bytes, p.img_bytes);
     hipStream_t st = as_stream(stream);
-    if (dtype == OFASR_BF16) return launch_conv2d<bf16_t>(name, x, w, y, N, Cin, Cout, H, W, K, dgrad, ws, st);
-    return launch_conv2d<f16_t>(name, x, w, y, N, Cin, Cout, H, W, K, dgrad, ws, st);
+    if (so.partial)
+        OFASR_REQUIRE(!dgrad && so.P == conv_stat_units(N, Cin, Cout, H, W, K), OFASR_ERR_INVALID_ARG,
+                      "%s: statistics unit count %d does not match the launch", name, so.P);
+    if (dtype == OFASR_BF16) return launch_conv2d<bf16_t>(name, x, w, y, N, Cin, Cout, H, W, K, dgrad, ws, st, so);
+    return launch_conv2d<f16_t>(name, x, w, y, N, Cin, Cout, H, W, K, dgrad, ws, st, so);
 }
 
 }  // namespace ofasr
@@ -744,8 +783,24 @@ OFASR_EXPORT int ofasr_conv2d_infer_run(const void* x, void* y, int64_t N, int64
                   name, operand_bytes, cv_infer_bytes(Cin, Cout, K));
     const float* ss = reinterpret_cast<const float*>((const char*)operands + (cv_plan(Cin, Cout, K, 0).img_bytes + 255) / 256 * 256);
     hipStream_t st = as_stream(stream);
-    if (dtype == OFASR_BF16) return launch_conv_run<bf16_t>(name, x, operands, y, N, Cin, Cout, H, W, K, 0, CvEpi{ss, act}, st);
-    return launch_conv_run<f16_t>(name, x, operands, y, N, Cin, Cout, H, W, K, 0, CvEpi{ss, act}, st);
+    if (dtype == OFASR_BF16) return launch_conv_run<bf16_t>(name, x, operands, y, N, Cin, Cout, H, W, K, 0, CvEpi{ss, act, nullptr, 0}, st);
+    return launch_conv_run<f16_t>(name, x, operands, y, N, Cin, Cout, H, W, K, 0, CvEpi{ss, act, nullptr, 0}, st);
+}
+
+// forward that also leaves the BatchNorm statistics partials of its output: partial[Cout][units] (sum, sum of squares),
+// units = ofasr_conv2d_stat_units(...); fold them with ofasr_bn_finalize_cp / ofasr_bn_fwd_cp
+OFASR_EXPORT int ofasr_conv2d_stat_units(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || !(K == 3 || K == 5)) return 0;
+    return conv_stat_units(N, Cin, Cout, H, W, K);
+}
+
+OFASR_EXPORT int ofasr_conv2d_fwd_stat(const void* x, const float* w, void* y, int64_t N, int64_t Cin, int64_t Cout, int64_t H,
+                                       int64_t W, int K, int dtype, void* partial, int64_t units, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    OFASR_REQUIRE(partial != nullptr && units > 0 && units <= INT32_MAX, OFASR_ERR_INVALID_ARG,
+                  "ofasr_conv2d_fwd_stat: null / empty statistics buffer");
+    return conv2d_entry("ofasr_conv2d_fwd_stat", x, w, y, N, Cin, Cout, H, W, K, dtype, 0, workspace, workspace_bytes, stream,
+                        StatOut{(float2*)partial, (int)units});
 }
 
 OFASR_EXPORT int ofasr_conv2d_dgrad(const void* dy, const float* w, void* dx, int64_t N, int64_t Cin, int64_t Cout,

@@ -98,6 +98,55 @@ __global__ void __launch_bounds__(256) ps_r2_kernel(const uint4* __restrict__ sr
     }
 }
 
+// BatchNorm apply + PixelShuffle(2) in one pass (ConvLayer with act_func "pixelshuffle": conv -> BN -> PixelShuffle,
+// reference ofa/layers.py:120-151, ofa_mbs4.py:111-123): a thread loads the same 8 pixels of the 4 source channels of one
+// output channel, applies each channel's (v - mean) * scale + beta (bn_act_fwd_kernel's arithmetic: beta = shift +
+// mean * scale) and writes two 32-byte runs of the up-sampled plane.  16-bit tensors.
+template <typename T>
+__device__ __forceinline__ uint4 ps_bn8(uint4 v, float mu, float sc, float be) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float lo, hi;
+        unpack2<T>(w[i], lo, hi);
+        o[i] = pack2<T>(fmaf(lo - mu, sc, be), fmaf(hi - mu, sc, be));
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) ps_r2_bn_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                       const float* __restrict__ mean, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int64_t items, int Cout, int H,
+                                                       int Wq) {
+    const int64_t plane = (int64_t)H * Wq;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t nc = it / plane;
+        const int64_t rem = it - nc * plane;
+        const int h = (int)(rem / Wq);
+        const int wq = (int)(rem - (int64_t)h * Wq);
+        const int c0 = 4 * (int)(nc % Cout);
+        const int64_t lr0 = nc * 4 * plane + rem;
+        const int64_t hr0 = nc * 4 * plane + ((int64_t)(2 * h) * (2 * Wq)) + 2 * wq;
+        uint4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = src[lr0 + j * plane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float mu = mean[c0 + j], sc = scale[c0 + j];
+            v[j] = ps_bn8<T>(v[j], mu, sc, fmaf(mu, sc, shift[c0 + j]));
+        }
+        uint4 lo, hi;
+        Interleave<2>::zip(v[0], v[1], lo, hi);
+        dst[hr0] = lo;
+        dst[hr0 + 1] = hi;
+        Interleave<2>::zip(v[2], v[3], lo, hi);
+        dst[hr0 + 2 * Wq] = lo;
+        dst[hr0 + 2 * Wq + 1] = hi;
+    }
+}
+
 template <bool SHUFFLE>
 static int launch(const void* x, void* y, int64_t N, int64_t C, int64_t H, int64_t W, int r, int es,
                   hipStream_t st) {
@@ -153,4 +202,33 @@ OFASR_EXPORT int ofasr_pixel_shuffle(const void* x, void* y, int64_t N, int64_t 
 OFASR_EXPORT int ofasr_pixel_unshuffle(const void* x, void* y, int64_t N, int64_t C, int64_t H, int64_t W,
                                        int r, int elem_size, void* stream) {
     return ofasr::launch<false>(x, y, N, C, H, W, r, elem_size, ofasr::as_stream(stream));
+}
+
+// y[N, C, 2H, 2W] = PixelShuffle(2)(BN(x[N, 4C, H, W])) with finalized statistics (stats = mean | invstd | scale | shift,
+// 4*C_in floats as ofasr_bn_finalize_cp / ofasr_bn_fwd leave them); f16 / bf16, W % 8 == 0, 16-byte aligned tensors
+OFASR_EXPORT int ofasr_pixel_shuffle2_bn(const void* x, void* y, const float* stats, int64_t N, int64_t C, int64_t H, int64_t W,
+                                         int dtype, void* stream) {
+    using namespace ofasr;
+    const char* name = "ofasr_pixel_shuffle2_bn";
+    OFASR_REQUIRE(x && y && stats, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, OFASR_ERR_INVALID_ARG, "%s: bad shape", name);
+    OFASR_REQUIRE(dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_UNSUPPORTED, "%s: 16-bit tensors only", name);
+    OFASR_REQUIRE(W % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0,
+                  OFASR_ERR_UNSUPPORTED, "%s: needs W %% 8 == 0 and 16-byte aligned tensors", name);
+    OFASR_REQUIRE(C <= INT32_MAX / 4 && 2 * H <= INT32_MAX && 2 * W <= INT32_MAX, OFASR_ERR_UNSUPPORTED, "%s: too large", name);
+    const int64_t Cin = 4 * C;
+    const float *mean = stats, *scale = stats + 2 * Cin, *shift = stats + 3 * Cin;
+    const int Wq = (int)(W / 8);
+    const int64_t items = N * C * H * Wq;
+    const int64_t blocks = cdiv(items, 256);
+    const int grid = (int)(blocks < 65536 ? blocks : 65536);
+    hipStream_t st = as_stream(stream);
+    prof_note(2.0 * 2.0 * (double)N * (double)Cin * (double)H * (double)W, 0.0);
+    if (dtype == OFASR_BF16)
+        OFASR_LAUNCH((ps_r2_bn_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const uint4*)x, (uint4*)y, mean, scale, shift, items,
+                     (int)C, (int)H, Wq);
+    else
+        OFASR_LAUNCH((ps_r2_bn_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (const uint4*)x, (uint4*)y, mean, scale, shift, items,
+                     (int)C, (int)H, Wq);
+    return check_launch(name);
 }

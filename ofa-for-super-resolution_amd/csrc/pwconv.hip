@@ -367,43 +367,7 @@ __device__ __forceinline__ void add_px(const T* __restrict__ src, int px, int HW
     }
 }
 
-// BatchNorm statistics epilogue: v[reg] is this lane's partial sum for accumulator register reg (row acc_row(reg, h)).
-// A reduce-scatter over the 32 lanes of the half-wave (16 shuffles instead of 16 x 5) leaves in v[0] the total of
-// register rho(c) = 8*b4 + 4*b3 + 2*b2 + b1 (bits of the lane's column c), identical in the two lanes of a b0 pair.
-__device__ __forceinline__ void half_wave_row_sums(float (&v)[16], float (&w)[16], int c) {
-    // both quantities level by level, so the 2 x (8 + 4 + 2 + 1 + 1) cross-lane moves form 5 dependent rounds, not 10
-    const bool b4 = c & 16, b3 = c & 8, b2 = c & 4, b1 = c & 2;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const float kv = b4 ? v[r + 8] : v[r], sv = b4 ? v[r] : v[r + 8];
-        const float kw = b4 ? w[r + 8] : w[r], sw = b4 ? w[r] : w[r + 8];
-        v[r] = kv + __shfl_xor(sv, 16, 64);
-        w[r] = kw + __shfl_xor(sw, 16, 64);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float kv = b3 ? v[r + 4] : v[r], sv = b3 ? v[r] : v[r + 4];
-        const float kw = b3 ? w[r + 4] : w[r], sw = b3 ? w[r] : w[r + 4];
-        v[r] = kv + __shfl_xor(sv, 8, 64);
-        w[r] = kw + __shfl_xor(sw, 8, 64);
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const float kv = b2 ? v[r + 2] : v[r], sv = b2 ? v[r] : v[r + 2];
-        const float kw = b2 ? w[r + 2] : w[r], sw = b2 ? w[r] : w[r + 2];
-        v[r] = kv + __shfl_xor(sv, 4, 64);
-        w[r] = kw + __shfl_xor(sw, 4, 64);
-    }
-    {
-        const float kv = b1 ? v[1] : v[0], sv = b1 ? v[0] : v[1];
-        const float kw = b1 ? w[1] : w[0], sw = b1 ? w[0] : w[1];
-        v[0] = kv + __shfl_xor(sv, 2, 64);
-        w[0] = kw + __shfl_xor(sw, 2, 64);
-    }
-    v[0] += __shfl_xor(v[0], 1, 64);
-    w[0] += __shfl_xor(w[0], 1, 64);
-}
-__device__ __forceinline__ int half_wave_row_reg(int c) { return ((c >> 4) & 1) * 8 + ((c >> 3) & 1) * 4 + ((c >> 2) & 1) * 2 + ((c >> 1) & 1); }
+// (half_wave_row_sums / half_wave_row_reg: ofasr_common.h)
 
 // statistics of NSUB accumulator sub-tiles (PX = NSUB adjacent pixels per lane starting at px) of one 32-row block
 template <typename T, int NSUB>

@@ -122,6 +122,19 @@ class ConvLayer(My2DLayer):
         if not (ops.FUSED_BN and self.ops_order == "weight_bn_act" and self.use_bn and self.dropout_rate == 0
                 and x.is_cuda):
             return super().forward(x)
+        if self.bn.training:   # BatchNorm statistics from the conv's epilogue, PixelShuffle(2) as the BN apply's store
+            act = self._modules.get("act", None)
+            if act is None:
+                code, rest = ops.ACT_NONE, None
+            elif self.act_func == "relu6":
+                code, rest = ops.ACT_RELU6, None
+            elif self.act_func == "pixelshuffle" and getattr(act, "upscale_factor", None) == 2:
+                code, rest = ops.ACT_PIXEL_SHUFFLE2, None
+            else:
+                code, rest = ops.ACT_NONE, act
+            y = ops.conv_bn_act_train(x, self.conv, self.bn, code)
+            if y is not None:
+                return y if rest is None else rest(y)
         x = ops.conv2d(x, self.conv)
         if self.act_func == "relu6":
             return ops.bn_act(x, self.bn, ops.ACT_RELU6)

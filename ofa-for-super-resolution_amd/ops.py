@@ -383,28 +383,78 @@ class BNActFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, stats, res = ctx.saved_tensors
-        training, act, has_res, wshape = ctx.meta
-        N, C, H, W = x.shape
-        HW = H * W
-        L = _C.lib()
-        dy = dy.contiguous()
-        dx = torch.empty_like(x)
-        # the kernel writes channels [0, C); only a sliced BN (C < num_features) needs the zero tail
-        full = int(wshape[0]) == C
-        gb = (torch.empty if full else torch.zeros)((2,) + tuple(wshape), dtype=torch.float32, device=x.device)
-        dgamma, dbeta = gb[0], gb[1]
-        dres = None
-        if has_res:
-            # without an activation the residual gradient IS dy; with one it is the masked dy
-            dres = torch.empty_like(x) if act != ACT_NONE else dy
-        wst, wsp, wsn = _ws(L.ofasr_bn_act_bwd_workspace(N, C), x.device)
-        rp = _p(res) if res is not None else ctypes.c_void_p(None)
-        drp = _p(dres) if (has_res and act != ACT_NONE) else ctypes.c_void_p(None)
-        with _timed("bn_act_bwd", 5 * x.numel() * x.element_size()):
-            _C.check(L.ofasr_bn_act_bwd(_p(dy), _p(x), rp, _p(dx), drp, _p(stats[2]), _p(stats[3]), _p(stats[0]),
-                                        _p(stats[1]), _p(dgamma), _p(dbeta), N, C, HW, act, 1 if training else 0,
-                                        _dt(x), wsp, wsn, _stream()), "bn_act_bwd")
+        dx, dgamma, dbeta, dres = _bn_act_backward(x, stats, res, ctx.meta, dy)
         return dx, dgamma, dbeta, None, None, None, None, None, None, dres
+
+
+def _bn_act_backward(x, stats, res, meta, dy):
+    """(dx, dgamma, dbeta, dresidual) of act(BN(x) (+ residual)): reduction + fused apply (ofasr_bn_act_bwd)"""
+    training, act, has_res, wshape = meta
+    N, C, H, W = x.shape
+    HW = H * W
+    L = _C.lib()
+    dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    # the kernel writes channels [0, C); only a sliced BN (C < num_features) needs the zero tail
+    full = int(wshape[0]) == C
+    gb = (torch.empty if full else torch.zeros)((2,) + tuple(wshape), dtype=torch.float32, device=x.device)
+    dgamma, dbeta = gb[0], gb[1]
+    dres = None
+    if has_res:
+        # without an activation the residual gradient IS dy; with one it is the masked dy
+        dres = torch.empty_like(x) if act != ACT_NONE else dy
+    wst, wsp, wsn = _ws(L.ofasr_bn_act_bwd_workspace(N, C), x.device)
+    rp = _p(res) if res is not None else ctypes.c_void_p(None)
+    drp = _p(dres) if (has_res and act != ACT_NONE) else ctypes.c_void_p(None)
+    with _timed("bn_act_bwd", 5 * x.numel() * x.element_size()):
+        _C.check(L.ofasr_bn_act_bwd(_p(dy), _p(x), rp, _p(dx), drp, _p(stats[2]), _p(stats[3]), _p(stats[0]),
+                                    _p(stats[1]), _p(dgamma), _p(dbeta), N, C, HW, act, 1 if training else 0,
+                                    _dt(x), wsp, wsn, _stream()), "bn_act_bwd")
+    return dx, dgamma, dbeta, dres
+
+
+class BNActCPFn(Function):
+    """BatchNorm (+ReLU6 | + PixelShuffle(2)) of a conv output whose batch statistics the conv's epilogue already took
+    (Conv2dStatFn: [C][units] (sum, sum of squares) partials) -- ConvLayer in training mode, reference ofa/layers.py:
+    120-151.  act: ACT_NONE / ACT_RELU6 -> ofasr_bn_fwd_cp (fold + apply in one kernel); ACT_PIXEL_SHUFFLE2 ->
+    ofasr_bn_finalize_cp + ofasr_pixel_shuffle2_bn (the BN apply writes the up-sampled tensor: no shuffle pass).
+    Backward: the shuffle's inverse on the incoming gradient, then BNActFn's backward."""
+
+    @staticmethod
+    def forward(ctx, x, partial, weight, bias, running_mean, running_var, momentum, eps, act):
+        _gpu(x, weight, bias, running_mean, running_var)
+        N, C, H, W = x.shape
+        L = _C.lib()
+        w, b = _f32_param(weight), _f32_param(bias)
+        stats = torch.empty((4, C), dtype=torch.float32, device=x.device)
+        units = partial.shape[1]
+        if act == ACT_PIXEL_SHUFFLE2:
+            y = torch.empty((N, C // 4, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
+            _C.check(L.ofasr_bn_finalize_cp(_p(partial), units, C, float(N * H * W), _p(w), _p(b), _p(running_mean),
+                                            _p(running_var), float(momentum), float(eps), 1, _p(stats), _stream()),
+                     "bn_finalize_cp")
+            with _timed("bn_pixel_shuffle", 2 * x.numel() * x.element_size()):
+                _C.check(L.ofasr_pixel_shuffle2_bn(_p(x), _p(y), _p(stats), N, C // 4, H, W, _dt(x), _stream()),
+                         "pixel_shuffle2_bn")
+        else:
+            y = torch.empty_like(x)
+            with _timed("bn_fwd_cp", 2 * x.numel() * x.element_size()):
+                _C.check(L.ofasr_bn_fwd_cp(_p(x), None, _p(y), _p(partial), units, _p(w), _p(b), _p(running_mean),
+                                           _p(running_var), float(momentum), float(eps), 1, _p(stats), N, C, H * W, int(act),
+                                           _dt(x), _stream()), "bn_fwd_cp")
+        ctx.save_for_backward(x, stats)
+        ctx.meta = (True, ACT_NONE if act == ACT_PIXEL_SHUFFLE2 else act, False, tuple(weight.shape))
+        ctx.shuffled = act == ACT_PIXEL_SHUFFLE2
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, stats = ctx.saved_tensors
+        if ctx.shuffled:
+            dy = _shuffle_raw(dy.contiguous(), 2, True)
+        dx, dgamma, dbeta, _ = _bn_act_backward(x, stats, None, ctx.meta, dy)
+        return dx, None, dgamma, dbeta, None, None, None, None, None
 
 
 def bn_act(x, bn, act=ACT_NONE, residual=None):
@@ -842,58 +892,116 @@ class Conv2dFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        return _conv2d_backward(ctx, dy)
+
+
+class Conv2dStatFn(Function):
+    """Conv2dFn whose forward also returns the BatchNorm statistics partials of its output (ofasr_conv2d_fwd_stat:
+    [Cout][units] (sum, sum of squares) from the kernel's epilogue) for BNActCPFn -- no pass over the conv output for
+    statistics."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
         N, Cin, H, W = x.shape
         Cout, _, K, _ = weight.shape
-        dy = dy.contiguous()
+        ctx.dgrad_hip = True
         L = _C.lib()
-        dx = dw = None
-        if not ctx.dgrad_hip:
-            w16 = weight.to(x.dtype)
-            dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w16, None, [1, 1], [K // 2, K // 2], [1, 1], False,
-                                                            [0, 0], 1, [ctx.needs_input_grad[0],
-                                                                        ctx.needs_input_grad[1], False])
-            return dx, (dw.float() if dw is not None else None), None
-        # weight gradient on a side stream beside the input gradient (both read dy; neither alone keeps HBM busy
-        # through its load / drain phases).  Buffers are allocated on the current stream; fork before, join after.
-        cur = torch.cuda.current_stream(x.device)
-        side = _side_stream(x.device) if (ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and SIDE_STREAM) else None
-        # deferred mode: the weight gradient goes to the library's side stream and is joined (with the composite
-        # blocks' weight gradients) once at the end of the backward pass -- it overlaps whatever backward runs next
-        defer = False
-        if ctx.needs_input_grad[1] and side is None and CONV_DEFER_WGRAD and H * W >= CONV_DEFER_MIN_HW \
-                and _lib_side_stream(x.device) is not None:
-            defer = _defer_this_backward((weight,))
-            if defer:
-                side = _lib_side_stream(x.device)
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
-            wst2, wsp2, wsn2 = _ws(L.ofasr_conv2d_wgrad_workspace(N, Cin, Cout, H, W, K), x.device)
-            if side is not None:
-                side.wait_stream(cur)
-            with torch.cuda.stream(side if side is not None else cur):
-                with _timed("conv2d_wgrad_%dto%d_k%d" % (Cin, Cout, K), (x.numel() + dy.numel()) * x.element_size(),
-                            2 * N * H * W * Cin * Cout * K * K):
-                    _C.check(L.ofasr_conv2d_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Cout, H, W, K, _dt(x), wsp2, wsn2,
-                                                  _stream()), "conv2d_wgrad")
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            wst, wsp, wsn = _ws(L.ofasr_conv2d_workspace(Cin, Cout, K, 1), x.device)
-            with _timed("conv2d_dgrad_%dto%d_k%d" % (Cout, Cin, K), (x.numel() + dy.numel()) * x.element_size(),
-                        2 * N * H * W * Cin * Cout * K * K):
-                _C.check(L.ofasr_conv2d_dgrad(_p(dy), _p(weight), _p(dx), N, Cin, Cout, H, W, K, _dt(x), wsp, wsn,
-                                              _stream()), "conv2d_dgrad")
+        y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=x.device)
+        units = L.ofasr_conv2d_stat_units(N, Cin, Cout, H, W, K)
+        partial = torch.empty((Cout, units, 2), dtype=torch.float32, device=x.device)
+        wst, wsp, wsn = _ws(L.ofasr_conv2d_workspace(Cin, Cout, K, 0), x.device)
+        with _timed("conv2d_fwd_%dto%d_k%d" % (Cin, Cout, K), (x.numel() + y.numel()) * x.element_size(),
+                    2 * N * H * W * Cin * Cout * K * K):
+            _C.check(L.ofasr_conv2d_fwd_stat(_p(x), _p(weight), _p(y), N, Cin, Cout, H, W, K, _dt(x), _p(partial), units,
+                                             wsp, wsn, _stream()), "conv2d_fwd_stat")
+        ctx.save_for_backward(x, weight)
+        ctx.mark_non_differentiable(partial)
+        return y, partial
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, _dpartial):
+        return _conv2d_backward(ctx, dy)[:2]
+
+
+def _conv2d_backward(ctx, dy):
+    """input / weight gradient of the static conv (shared by Conv2dFn and Conv2dStatFn)"""
+    x, weight = ctx.saved_tensors
+    N, Cin, H, W = x.shape
+    Cout, _, K, _ = weight.shape
+    dy = dy.contiguous()
+    L = _C.lib()
+    dx = dw = None
+    if not ctx.dgrad_hip:
+        w16 = weight.to(x.dtype)
+        dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w16, None, [1, 1], [K // 2, K // 2], [1, 1], False,
+                                                        [0, 0], 1, [ctx.needs_input_grad[0],
+                                                                    ctx.needs_input_grad[1], False])
+        return dx, (dw.float() if dw is not None else None), None
+    # weight gradient on a side stream beside the input gradient (both read dy; neither alone keeps HBM busy
+    # through its load / drain phases).  Buffers are allocated on the current stream; fork before, join after.
+    cur = torch.cuda.current_stream(x.device)
+    side = _side_stream(x.device) if (ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and SIDE_STREAM) else None
+    # deferred mode: the weight gradient goes to the library's side stream and is joined (with the composite
+    # blocks' weight gradients) once at the end of the backward pass -- it overlaps whatever backward runs next
+    defer = False
+    if ctx.needs_input_grad[1] and side is None and CONV_DEFER_WGRAD and H * W >= CONV_DEFER_MIN_HW \
+            and _lib_side_stream(x.device) is not None:
+        defer = _defer_this_backward((weight,))
         if defer:
-            _Deferred.keep.append((x, dy, dw, wst2, weight))
-            _Deferred.grads.append((weight, dw))
-            _Deferred.ext_used.add(torch.device(x.device).index or 0)
-            return dx, None, None
+            side = _lib_side_stream(x.device)
+    if ctx.needs_input_grad[1]:
+        dw = torch.empty_like(weight)
+        wst2, wsp2, wsn2 = _ws(L.ofasr_conv2d_wgrad_workspace(N, Cin, Cout, H, W, K), x.device)
         if side is not None:
-            cur.wait_stream(side)
-        return dx, dw, None
+            side.wait_stream(cur)
+        with torch.cuda.stream(side if side is not None else cur):
+            with _timed("conv2d_wgrad_%dto%d_k%d" % (Cin, Cout, K), (x.numel() + dy.numel()) * x.element_size(),
+                        2 * N * H * W * Cin * Cout * K * K):
+                _C.check(L.ofasr_conv2d_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Cout, H, W, K, _dt(x), wsp2, wsn2,
+                                              _stream()), "conv2d_wgrad")
+    if ctx.needs_input_grad[0]:
+        dx = torch.empty_like(x)
+        wst, wsp, wsn = _ws(L.ofasr_conv2d_workspace(Cin, Cout, K, 1), x.device)
+        with _timed("conv2d_dgrad_%dto%d_k%d" % (Cout, Cin, K), (x.numel() + dy.numel()) * x.element_size(),
+                    2 * N * H * W * Cin * Cout * K * K):
+            _C.check(L.ofasr_conv2d_dgrad(_p(dy), _p(weight), _p(dx), N, Cin, Cout, H, W, K, _dt(x), wsp, wsn,
+                                          _stream()), "conv2d_dgrad")
+    if defer:
+        _Deferred.keep.append((x, dy, dw, wst2, weight))
+        _Deferred.grads.append((weight, dw))
+        _Deferred.ext_used.add(torch.device(x.device).index or 0)
+        return dx, None, None
+    if side is not None:
+        cur.wait_stream(side)
+    return dx, dw, None
 
 
 ACT_PIXEL_SHUFFLE2 = 2   # ofasr_conv2d_infer_run's act codes: 0 none, 1 ReLU6 (= ACT_RELU6), 2 PixelShuffle(2) store
+CONV_BN_EPILOGUE = os.environ.get("OFASR_CONV_BN_EPILOGUE", "1") != "0"
+
+
+def conv_bn_act_train(x, conv, bn, act):
+    """training-mode ConvLayer: conv (BatchNorm statistics from its epilogue) -> BatchNorm apply (+ ReLU6, or with the
+    PixelShuffle(2) as its store), act in {ACT_NONE, ACT_RELU6, ACT_PIXEL_SHUFFLE2}.  One pass less over the conv output
+    per layer (two with the shuffle) than conv -> statistics -> apply -> shuffle.  Returns None when the layer is outside
+    what the kernels implement (16-bit activations, W % 8 == 0, BN tracking running statistics): the caller composes
+    conv2d + bn_act + activation."""
+    w = conv.weight
+    if torch.is_autocast_enabled() and x.is_cuda and x.dtype == torch.float32:
+        x = x.to(torch.get_autocast_dtype("cuda"))
+    if (not CONV_BN_EPILOGUE or not x.is_cuda or x.dtype not in (torch.float16, torch.bfloat16) or conv.bias is not None
+            or w.dtype != torch.float32 or not _conv_hip_ok(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
+            or x.shape[3] % 8 or not bn.training or not bn.track_running_stats or bn.weight is None
+            or bn.num_features != w.shape[0] or (act == ACT_PIXEL_SHUFFLE2 and w.shape[0] % 4)):
+        return None
+    factor = 0.0
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+        factor = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
+    y, partial = Conv2dStatFn.apply(x, w)
+    return BNActCPFn.apply(y, partial, bn.weight, bn.bias, bn.running_mean, bn.running_var, factor, bn.eps, act)
 
 
 def conv_bn_act_infer(x, conv, bn, act):

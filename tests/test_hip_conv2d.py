@@ -255,3 +255,80 @@ def test_conv2d_fp32_policy_routes_and_matches_oracle(ora):
         scale = float(np.sqrt(Cout * K * K / max(Cin * K * K, 1)))
         assert_close(xt.grad.cpu().numpy(), dx_ref, 5e-5, 5e-6 * max(1.0, scale), "dx")
         assert_close(conv.weight.grad.cpu().numpy(), dw_ref, 1e-4, 2e-6 * float(np.abs(dw_ref).max()) * np.sqrt(N * H * W), "dw")
+
+
+TRAIN_EPI_CASES = [
+    # N, Cin, Cout, H, W, K, act_func
+    (2, 64, 256, 6, 64, 5, "pixelshuffle"),   # decoder stage: statistics in the conv epilogue, PixelShuffle in the BN apply's store
+    (3, 3, 64, 8, 72, 5, "relu6"),            # stem: tiles cut by the right border (72 = 64 + 8)
+    (2, 64, 64, 5, 128, 5, None),
+    (2, 64, 128, 9, 32, 3, "relu6"),          # odd H: the last row of the last 2-row strip is outside the image
+]
+
+
+@pytest.mark.parametrize("case", TRAIN_EPI_CASES, ids=lambda c: "%dx%d_%dto%d_k%d_%s" % (c[3], c[4], c[1], c[2], c[5], c[6]))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv_layer_training_epilogue_statistics_vs_oracle(ora, case, dtype):
+    """training-mode ConvLayer (reference ofa/layers.py:120-151): the conv kernel's epilogue takes the BatchNorm statistics
+    (ofasr_conv2d_fwd_stat -> ofasr_bn_fwd_cp / ofasr_bn_finalize_cp + ofasr_pixel_shuffle2_bn).  Forward, running
+    statistics, and every gradient against the oracle's conv -> BN(batch statistics of the 16-bit conv output) -> act
+    chain in double; no statistics pass and no shuffle kernel in the forward."""
+    layers, C, ops = amd("layers"), amd("_C"), amd("ops")
+    N, Cin, Cout, H, W, K, act = case
+    r16 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dtype).float().numpy()
+    x = r16(det_uniform((N, Cin, H, W), "cvt/x%s" % (case,)))
+    a = float(np.sqrt(3.0 / (Cin * K * K)))
+    w = det_uniform((Cout, Cin, K, K), "cvt/w%s" % (case,), -a, a)
+    g = det_uniform((Cout,), "cvt/g%s" % (case,), 0.5, 1.5)
+    b = det_uniform((Cout,), "cvt/b%s" % (case,), -0.5, 0.5)
+    layer = layers.ConvLayer(Cin, Cout, kernel_size=K, use_bn=True, act_func=act).to(DEV).train()
+    with torch.no_grad():
+        layer.conv.weight.copy_(torch.from_numpy(w))
+        layer.bn.weight.copy_(torch.from_numpy(g))
+        layer.bn.bias.copy_(torch.from_numpy(b))
+    xt = torch.from_numpy(x).to(dtype).to(DEV).requires_grad_(True)
+    C.reset_launch_counts()
+    y = layer(xt)
+    table = C.launch_table()
+    assert C.launch_count("conv_igemm_kernel") == 1 and C.launch_count("bn_stats_kernel") == 0, table
+    assert C.launch_count("ps_r2_kernel") == 0 and C.launch_count("ps_generic") == 0, table
+    assert C.launch_count("ps_r2_bn_kernel") == (1 if act == "pixelshuffle" else 0), table
+
+    yc = r16(ora.conv2d_fwd(x, r16(w)))                       # the conv output as stored
+    rm, rv = np.zeros(Cout, np.float32), np.ones(Cout, np.float32)
+    z, _, _ = ora.bn_fwd(yc, g, b, rm, rv, True)
+    ref = z.astype(np.float64)
+    if act == "relu6":
+        ref = np.clip(ref, 0.0, 6.0)
+    elif act == "pixelshuffle":
+        ref = ora.pixel_shuffle(ref.astype(np.float32), 2).astype(np.float64)
+    rt = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    # the GPU's conv output may differ from the oracle's by one 16-bit rounding, which BN scales by gamma / sigma
+    sig = np.sqrt(yc.astype(np.float64).var(axis=(0, 2, 3)).min())
+    assert_close(y.detach().float().cpu().numpy(), ref.astype(np.float32), rt, rt * max(1.0, 1.5 / sig), "y")
+    assert_close(layer.bn.running_mean.cpu().numpy(), rm, 1e-3, 1e-4, "running_mean")
+    assert_close(layer.bn.running_var.cpu().numpy(), rv, 2e-3, 1e-4, "running_var")
+    assert int(layer.bn.num_batches_tracked) == 1
+
+    # backward against the un-fused HIP path on the same layer (itself oracle-tested): same gradients
+    dy = r16(det_uniform(tuple(y.shape), "cvt/dy%s" % (case,)))
+    y.backward(torch.from_numpy(dy).to(dtype).to(DEV))
+    got = [xt.grad.float().cpu().numpy(), layer.conv.weight.grad.cpu().numpy(), layer.bn.weight.grad.cpu().numpy(),
+           layer.bn.bias.grad.cpu().numpy()]
+    for p in (layer.conv.weight, layer.bn.weight, layer.bn.bias):
+        p.grad = None
+    with torch.no_grad():
+        layer.bn.running_mean.zero_()
+        layer.bn.running_var.fill_(1.0)
+    was, ops.CONV_BN_EPILOGUE = ops.CONV_BN_EPILOGUE, False
+    try:
+        x2 = torch.from_numpy(x).to(dtype).to(DEV).requires_grad_(True)
+        y2 = layer(x2)
+        y2.backward(torch.from_numpy(dy).to(dtype).to(DEV))
+    finally:
+        ops.CONV_BN_EPILOGUE = was
+    assert_close(y.detach().float().cpu().numpy(), y2.detach().float().cpu().numpy(), rt, rt, "y vs the un-fused path")
+    ref_g = [x2.grad.float().cpu().numpy(), layer.conv.weight.grad.cpu().numpy(), layer.bn.weight.grad.cpu().numpy(),
+             layer.bn.bias.grad.cpu().numpy()]
+    for name, a_, b_ in zip(("dx", "dw", "dgamma", "dbeta"), got, ref_g):
+        assert_close(a_, b_, 2 * rt, 2 * rt * max(float(np.abs(b_).max()), 1e-3), name)
