@@ -801,14 +801,20 @@ def _conv_hip_ok(x, weight, stride, padding, dilation, groups):
             and groups == 1 and padding == (k // 2, k // 2))
 
 
+CONV_F32_VENDOR = os.environ.get("OFASR_CONV_F32_VENDOR", "0") != "0"
+
+
 def _conv_f32_policy(cin, cout, k, H, W):
-    """(forward, input gradient, weight gradient) on the own fp32 kernels -- measured on MI355X at the S4 shapes
-    (tools/kbench.py --dtype f32, profiles/r02_kbench_f32.txt): the wide convs' forward / input gradient run at the
-    vendor kernels' rate (120 against 122 TFLOP/s on 64 -> 256 @128x128, 76 % of the fp32 matrix peak); the weight
-    gradient (67 against 119) and the 3-channel stem / head convs (a 32-row matrix tile for 3 channels) are slower, so
-    those stay on the vendor library for the regular training shapes.  Ragged sizes (Set14 evaluation) always run the
-    own kernels: the vendor's per-shape kernel search costs more than the convolution."""
-    if CONV_FORCE_HIP or W % 8 != 0 or H % 2 != 0:
+    """(forward, input gradient, weight gradient) on the own fp32 kernels.  Default: all three, always.
+
+    Measured on MI355X at the S4 shapes (tools/kbench.py --dtype f32, profiles/r02_kbench_f32.txt): the wide convs'
+    forward / input gradient run at the vendor kernels' rate (120 against 122 TFLOP/s on 64 -> 256 @128x128, 76 % of
+    the fp32 matrix peak); the weight gradient (67 against 119) and the 3-channel stem / head convs (a 32-row matrix tile
+    for 3 channels) are slower -- the fp32 training step is 26 ms with the own kernels everywhere and 22.4 ms with the
+    vendor's weight gradients and 3-channel convs.  OFASR_CONV_F32_VENDOR=1 selects that mix for regular training
+    shapes; it is not the default because the vendor library's per-shape kernel search costs minutes on a fresh
+    machine (260 s for the five shapes of one bench.py run) and because ragged Set14 sizes would search per image."""
+    if not CONV_F32_VENDOR or CONV_FORCE_HIP or W % 8 != 0 or H % 2 != 0:
         return True, True, True
     wide = min(cin, cout) >= 16
     return wide, wide, False

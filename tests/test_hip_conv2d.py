@@ -236,6 +236,14 @@ def test_conv2d_fp32_policy_routes_and_matches_oracle(ora):
     """_conv_f32_policy: a regular training shape takes the own forward / input gradient and the vendor weight gradient;
     a 3-channel conv the vendor kernels; a ragged width the own kernels for all three -- same results either way."""
     ops, C = amd("ops"), amd("_C")
+    was, ops.CONV_F32_VENDOR = ops.CONV_F32_VENDOR, True     # the opt-in mix (OFASR_CONV_F32_VENDOR=1); default: own kernels
+    try:
+        _policy_cases(ora, ops, C)
+    finally:
+        ops.CONV_F32_VENDOR = was
+
+
+def _policy_cases(ora, ops, C):
     for case, want in (((2, 64, 128, 8, 64, 5), (1, 1, 0)), ((1, 64, 3, 8, 64, 5), (0, 0, 0)), ((1, 64, 128, 8, 60, 5), (1, 1, 1))):
         N, Cin, Cout, H, W, K = case
         x = det_uniform((N, Cin, H, W), "cvp/x%s" % (case,))
