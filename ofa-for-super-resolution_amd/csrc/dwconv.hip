@@ -19,6 +19,8 @@
 // strips of 64 input columns producing 64-2*pad outputs.
 #include "ofasr_common.h"
 
+#include <type_traits>
+
 namespace ofasr {
 
 constexpr int DW_WAVES = 4;  // waves per block
@@ -1012,11 +1014,170 @@ static int conv_entry(const char* name, const void* x, const float* f, void* y, 
     }
 }
 
+// =================================================================================================
+// Depthwise weight gradient on the matrix cores (16-bit activations, W in {32, 64}, H a multiple of 16 up to 64).
+//     dW[ky][kx] = sum_{h,w} dY[h][w] * A[h + ky - P][w + kx - P]
+// For a kernel row ky the products of ALL column pairs are one GEMM over the image rows,
+//     M_ky[j][w] = sum_h A[h + ky - P][j] * dY[h][w]            (j input column, w output column),
+// and dW[ky][kx] is the sum of M_ky along the diagonal j - w = kx - P.  One workgroup owns a channel: wave ky keeps the
+// W x W accumulator tiles of its kernel row in registers across ALL images of the batch (the planes stream through a
+// double-buffered LDS image, both operands are transposing reads of row-major planes, the kernel-row shift is a row
+// offset into the plane image with P zero rows above and below), and the diagonals are summed ONCE at the end -- the
+// per-lane select-and-add that made a per-plane GEMM formulation no cheaper than the vector kernel is amortised over
+// the batch.  No split-K partials, no reduce launch: the kernel writes dW[c] itself.  16 * W/32 * W/32 MFMAs per
+// (image, kernel row) on 64 image rows; the planes are read once (2 tensors), i.e. the kernel is HBM-bound
+// (dw_wgrad_vec_kernel<7>: 4513 VALU instructions per wave against 1568 ideal, 113 us at N=16, 384 planes of 64x64).
+typedef __attribute__((ext_vector_type(4))) short dwg_s16x4;
+typedef __attribute__((address_space(3))) dwg_s16x4 dwg_lds_s16x4;
+constexpr int DWG_PITCH = 96;      // pixels per plane row in LDS: 192 bytes = 192 (mod 256), so the four rows of a
+                                   // transposing read sit on disjoint banks
+constexpr int DWG_THREADS = 512;
+
+// 8 k-values (plane rows kb .. kb+7) of plane column pos0 + (lane & 31): the A (row = column index) and B (column =
+// column index) operand layout of the 32x32x16 MFMA, by two transposing reads
+__device__ __forceinline__ dwm_s16x8 dwg_frag(const char* img, int pos0, int s, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int kb = 16 * s + 8 * (g >> 1);
+    const int colb = (pos0 + 16 * (g & 1) + 4 * pp) * 2;
+    const dwg_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dwg_lds_s16x4*)(img + (kb + q) * (DWG_PITCH * 2) + colb));
+    const dwg_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dwg_lds_s16x4*)(img + (kb + 4 + q) * (DWG_PITCH * 2) + colb));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <typename T, int K, int WT, bool XF>
+__global__ void __launch_bounds__(DWG_THREADS) dw_wgrad_mfma_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                    float* __restrict__ df, int N, int C, int H,
+                                                                    InputXf xf) {
+    constexpr int P = K / 2, W = 32 * WT;
+    constexpr int AROWS = 64 + 2 * P;
+    constexpr int A_BYTES = AROWS * DWG_PITCH * 2, G_BYTES = 64 * DWG_PITCH * 2;
+    __shared__ __attribute__((aligned(16))) char lds[2][A_BYTES + G_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = blockIdx.x;
+    float mu = 0.f, sc = 1.f, be = 0.f;
+    if constexpr (XF) {
+        mu = xf.mean[c];
+        sc = xf.scale[c];
+        be = fmaf(mu, sc, xf.shift[c]);
+    }
+    // zero halo rows of both A images (rows [0, P) and [P + H, P + H + P)); the data rows are rewritten per image
+    for (int e = tid; e < 2 * 2 * P * (DWG_PITCH / 8); e += DWG_THREADS) {
+        const int b = e / (2 * P * (DWG_PITCH / 8)), r2 = (e / (DWG_PITCH / 8)) % (2 * P), q = e % (DWG_PITCH / 8);
+        const int row = r2 < P ? r2 : P + H + (r2 - P);
+        *reinterpret_cast<uint4*>(lds[b] + row * (DWG_PITCH * 2) + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int quads = H * (W / 8);                 // 16-byte pieces per plane (<= 512)
+    const bool mine = tid < quads;
+    const int row = tid / (W / 8), col8 = tid - row * (W / 8);
+    const long long plane = (long long)H * W;
+    uint4 ga = make_uint4(0u, 0u, 0u, 0u), gg = ga;
+    auto load = [&](int n) {
+        if (mine) {
+            const long long off = ((long long)n * C + c) * plane + (long long)row * W + 8 * col8;
+            ga = *reinterpret_cast<const uint4*>(x + off);
+            gg = *reinterpret_cast<const uint4*>(dy + off);
+        }
+    };
+    auto store = [&](int b) {
+        if (mine) {
+            uint4 a = ga;
+            if constexpr (XF) {   // the activated operand relu6(BN(y)) as the matrix cores see it (16-bit)
+                const uint32_t w[4] = {ga.x, ga.y, ga.z, ga.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float lo, hi;
+                    unpack2<T>(w[i], lo, hi);
+                    o[i] = pack2<T>(fminf(fmaxf(fmaf(lo - mu, sc, be), 0.f), 6.f), fminf(fmaxf(fmaf(hi - mu, sc, be), 0.f), 6.f));
+                }
+                a = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+            *reinterpret_cast<uint4*>(lds[b] + (row + P) * (DWG_PITCH * 2) + col8 * 16) = a;
+            *reinterpret_cast<uint4*>(lds[b] + A_BYTES + row * (DWG_PITCH * 2) + col8 * 16) = gg;
+        }
+    };
+    dwm_f32x16 acc[WT][WT];
+#pragma unroll
+    for (int jb = 0; jb < WT; ++jb)
+#pragma unroll
+        for (int wb = 0; wb < WT; ++wb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[jb][wb][i] = 0.f;
+    const int ksteps = H / 16;
+    load(0);
+    for (int n = 0; n < N; ++n) {
+        const int b = n & 1;
+        store(b);
+        __syncthreads();      // image n visible; every wave is done with image n - 1 (the buffer image n + 1 will take)
+        if (n + 1 < N) load(n + 1);
+        if (wave < K) {
+            const char* ab = lds[b] + wave * (DWG_PITCH * 2);      // kernel row ky = wave: plane rows shifted by ky
+            const char* gb = lds[b] + A_BYTES;
+            for (int s = 0; s < ksteps; ++s) {
+                dwm_s16x8 af[WT], bf[WT];
+#pragma unroll
+                for (int jb = 0; jb < WT; ++jb) af[jb] = dwg_frag(ab, 32 * jb, s, lane);
+#pragma unroll
+                for (int wb = 0; wb < WT; ++wb) bf[wb] = dwg_frag(gb, 32 * wb, s, lane);
+#pragma unroll
+                for (int jb = 0; jb < WT; ++jb)
+#pragma unroll
+                    for (int wb = 0; wb < WT; ++wb) acc[jb][wb] = DwMma<T>::run(af[jb], bf[wb], acc[jb][wb]);
+            }
+        }
+    }
+    if (wave >= K) return;
+    // diagonals: accumulator (row r, column cc) of tile (jb, wb) is M[j = 32 jb + r][w = 32 wb + cc]; kx = j - w + P
+    float sum[K];
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) sum[kx] = 0.f;
+    const int cc = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int jb = 0; jb < WT; ++jb)
+#pragma unroll
+        for (int wb = 0; wb < WT; ++wb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                const int kx = 32 * (jb - wb) + r - cc + P;
+                const float v = acc[jb][wb][reg];
+#pragma unroll
+                for (int q = 0; q < K; ++q) sum[q] += (kx == q) ? v : 0.f;
+            }
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+        const float t = wave_sum(sum[kx]);
+        if (lane == 0) df[((long long)c * K + wave) * K + kx] = t;
+    }
+}
+
+static bool dw_wgrad_mfma_ok(const void* dy, const void* x, int64_t N, int64_t C, int64_t H, int64_t W, int K, size_t es) {
+    static const bool on = [] { const char* e = getenv("OFASR_DW_WGRAD_MFMA"); return !(e && e[0] == '0'); }();
+    return on && es == 2 && (K == 3 || K == 5 || K == 7) && (W == 32 || W == 64) && H % 16 == 0 && H >= 16 && H <= 64 &&
+           N >= 1 && C >= 1 && C <= INT32_MAX && N <= INT32_MAX &&
+           ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+}
+
 template <typename T, bool XF = false>
 static int launch_wgrad(const char* name, const void* dy, const void* x, float* df, int64_t N, int64_t C,
                         int64_t H, int64_t W, int K, float* ws, hipStream_t st, InputXf xf = InputXf{}) {
     prof_note(2.0 * sizeof(T) * (double)N * (double)C * (double)H * (double)W + 4.0 * (double)C * K * K,
               2.0 * K * K * (double)N * (double)C * (double)H * (double)W);
+    if constexpr (!std::is_same<T, float>::value) {
+        if (dw_wgrad_mfma_ok(dy, x, N, C, H, W, K, sizeof(T))) {
+#define OFASR_DWGM(KK, WT)                                                                                          \
+    OFASR_LAUNCH((dw_wgrad_mfma_kernel<T, KK, WT, XF>), dim3((unsigned)C), dim3(DWG_THREADS), 0, st, (const T*)dy,   \
+                 (const T*)x, df, (int)N, (int)C, (int)H, xf)
+            if (W == 64) {
+                if (K == 7) OFASR_DWGM(7, 2); else if (K == 5) OFASR_DWGM(5, 2); else OFASR_DWGM(3, 2);
+            } else {
+                if (K == 7) OFASR_DWGM(7, 1); else if (K == 5) OFASR_DWGM(5, 1); else OFASR_DWGM(3, 1);
+            }
+#undef OFASR_DWGM
+            return check_launch(name);
+        }
+    }
     {
         VecGeom vg;
         if (vec_geom(H, W, (int)sizeof(T), 4, dy, x, vg)) {

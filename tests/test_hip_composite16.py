@@ -157,7 +157,11 @@ def test_composite_block_16bit_vs_oracle(ora, case, bstat):
         assert ran(bwd_table, "pw_fanin_pipe_kernel<%s, false, true, true>" % T) == 1, bwd_table   # expand dgrad (+dout)
         assert ran(bwd_table, "pw_wgrad_direct_kernel<%s, 1>" % T) + ran(bwd_table, "pw_wgrad_direct_kernel<%s, 2>" % T) == 1
         assert ran(bwd_table, "pw_wgrad_direct_kernel<%s, 0>" % T) == 1, bwd_table
-        assert ran(bwd_table, "dw_wgrad_vec_kernel<%s, %d, true>" % (T, K)) == 1, bwd_table
+        if Ww in (32, 64) and Hh % 16 == 0 and Hh <= 64:   # depthwise weight gradient on the matrix cores, no reduce launch
+            assert ran(bwd_table, "dw_wgrad_mfma_kernel<%s, %d, %d, true>" % (T, K, Ww // 32)) == 1, bwd_table
+            assert ran(bwd_table, "dw_wgrad_vec") == 0, bwd_table
+        else:
+            assert ran(bwd_table, "dw_wgrad_vec_kernel<%s, %d, true>" % (T, K)) == 1, bwd_table
         nstat = ran(bwd_table, "bn_bwd_coef_cp_kernel")
         assert ran(bwd_table, "bn_bwd_reduce_kernel") == 3 - nstat and ran(bwd_table, "bn_bwd_apply_kernel") == 1
         assert ran(bwd_table, "bn_bwd_coef_kernel") == 2 - nstat
@@ -258,7 +262,10 @@ def test_composite_block_16bit_vs_oracle(ora, case, bstat):
     # fp32 value in the vector kernel (folded path); after an apply pass it reads the stored tensor
     dy2_in = d2.astype(np.float32) if (folded_bwd and not dw_mma) else dy2_gpu
     da1, _ = ora.dwconv_bwd(dy2_in, a1_in, c16.r16(f_gpu, dtype) if dw_mma else f_gpu)
-    _, df = ora.dwconv_bwd(dy2_gpu, a1.astype(np.float32), f_gpu)        # the weight-gradient kernel reads a1 in fp32
+    # the weight-gradient kernel on the matrix cores sees the activated operand rounded to 16 bits; the vector kernel reads
+    # it in fp32
+    wg_mma = ran(bwd_table, "dw_wgrad_mfma_kernel") > 0
+    _, df = ora.dwconv_bwd(dy2_gpu, c16.r16(a1, dtype) if wg_mma else a1.astype(np.float32), f_gpu)
     dwdw_ref, dm_ref = ora.ktransform_bwd(df, wdw, mid, K, ks_set, mats)
     close32(grads[pfx + "depth_conv.conv.conv.weight"], dwdw_ref, "d(depthwise weight)")
     for nm in ("7to5", "5to3"):
