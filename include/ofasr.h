@@ -168,8 +168,11 @@ int ofasr_bn_act_bwd(const void* dy, const void* x, const void* residual, void* 
  * project 1x1 -> BN (+ x)).  Exists to keep the host (Python) cost per block at one FFI call: at the
  * MB stack's sizes the step is otherwise bound by ~100 Python-side launches per block, not by the GPU.
  *
- * act_buf  (activation dtype)  [y1 | a1 | y2 | a2] 4*N*mid*HW elements, then [y3 | out] 2*N*Cout*HW
- *          y = pre-BN conv outputs, a = activated tensors; `out` is the block output.  Kept for backward.
+ * act_buf  (activation dtype, 16-byte aligned)  ofasr_mbconv_act_elems(d) elements, kept for backward:
+ *          [y1 | y2] 2*N*mid*HW then [y3 | out] 2*N*Cout*HW when the block takes the fused 16-bit path (BN + ReLU6 applied
+ *          in the consumers' loads: the activated tensors are never written and get no room), otherwise
+ *          [y1 | a1 | y2 | a2] 4*N*mid*HW then [y3 | out].  y = pre-BN conv outputs, a = activated tensors; `out`, the
+ *          block output, is always the last N*Cout*HW elements.  The choice is a function of the descriptor alone.
  * stat_buf (fp32) per BN i in {expand, depthwise, project}: mean | invstd | scale | shift (4*C_i, C = mid, mid,
  *          Cout), then the active depthwise filter f [mid*K*K].
  * bwd: tmp_buf (activation dtype) 3*N*mid*HW + N*Cout*HW elements of scratch; every gradient tensor is
@@ -210,6 +213,7 @@ typedef struct {
 
 size_t ofasr_mbconv_workspace(const ofasr_mbconv_desc* d);
 size_t ofasr_mbconv_stat_floats(const ofasr_mbconv_desc* d);
+size_t ofasr_mbconv_act_elems(const ofasr_mbconv_desc* d);
 int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, void* act_buf, float* stat_buf, void* workspace,
                      size_t workspace_bytes, void* stream);
 int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, const void* act_buf, const float* stat_buf,

@@ -87,6 +87,7 @@ SIGNATURES = {
     "ofasr_conv2d_f32_wgrad_workspace": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int]),
     "ofasr_conv2d_f32_wgrad": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_vp, _c_sz, _c_vp]),
     "ofasr_mbconv_workspace": (_c_sz, [_c_vp]),
+    "ofasr_mbconv_act_elems": (_c_sz, [_c_vp]),
     "ofasr_mbconv_stat_floats": (_c_sz, [_c_vp]),
     "ofasr_mbconv_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "ofasr_mbconv_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),

@@ -182,13 +182,27 @@ static InputXf xf_of(const float* stat_buf, int which, int64_t mid, int64_t cout
 // BN1/BN2 + ReLU6 are applied by the consumer's loads (a1, a2 are never written) when the vector depthwise and the
 // aligned 16-bit pointwise kernels apply to the block; forward and backward take the same decision from the
 // descriptor and the (caller-provided) buffer addresses.
-static bool fuse_apply(const ofasr_mbconv_desc* d, const MbSizes& s, const void* act_buf) {
-    const char* a = (const char*)act_buf;
-    const void* y1 = a;
-    const void* y2 = a + 2 * s.mid_elems * s.es;
-    const void* y3 = a + 4 * s.mid_elems * s.es;
-    return dwconv_xf_supported(y1, y2, d->H, d->W, d->K, d->dtype) &&
-           pwconv_xf_supported(y2, y3, d->H * d->W, d->dtype);
+// The decision is a function of the descriptor alone (act_buf must then be 16-byte aligned), because it also fixes the
+// layout of act_buf: the fused path keeps y1 | y2 | y3 | out only (the activated tensors a1, a2 are never written, so
+// they get no room: 2*mid + 2*Cout instead of 4*mid + 2*Cout channels per pixel held for the backward).
+struct ActLayout {
+    bool fused;
+    size_t y1, a1, y2, a2, y3, out, total;   // element offsets; a1 / a2 are meaningless when fused
+};
+static ActLayout act_layout(const ofasr_mbconv_desc* d, const MbSizes& s) {
+    ActLayout L;
+    const char* base = reinterpret_cast<const char*>(uintptr_t(4096));   // alignment of a conforming act_buf
+    L.fused = dwconv_xf_supported(base, base + s.mid_elems * s.es, d->H, d->W, d->K, d->dtype) &&
+              pwconv_xf_supported(base + s.mid_elems * s.es, base + 2 * s.mid_elems * s.es, d->H * d->W, d->dtype);
+    if (L.fused) {
+        L.y1 = 0; L.y2 = s.mid_elems; L.y3 = 2 * s.mid_elems; L.out = 2 * s.mid_elems + s.out_elems;
+        L.a1 = L.a2 = 0;
+    } else {
+        L.y1 = 0; L.a1 = s.mid_elems; L.y2 = 2 * s.mid_elems; L.a2 = 3 * s.mid_elems; L.y3 = 4 * s.mid_elems;
+        L.out = 4 * s.mid_elems + s.out_elems;
+    }
+    L.total = L.out + s.out_elems;
+    return L;
 }
 
 }  // namespace ofasr
@@ -198,6 +212,11 @@ using namespace ofasr;
 OFASR_EXPORT size_t ofasr_mbconv_workspace(const ofasr_mbconv_desc* d) {
     if (!d || d->N <= 0) return 0;
     return mb_sizes(d).total;
+}
+
+OFASR_EXPORT size_t ofasr_mbconv_act_elems(const ofasr_mbconv_desc* d) {
+    if (!d || d->N <= 0) return 0;
+    return act_layout(d, mb_sizes(d)).total;
 }
 
 OFASR_EXPORT size_t ofasr_mbconv_stat_floats(const ofasr_mbconv_desc* d) {
@@ -216,15 +235,18 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
                   name, workspace_bytes, s.total);
     const int64_t HW = d->H * d->W;
     char* a = (char*)act_buf;
-    void* y1 = a;
-    void* a1 = a + s.mid_elems * s.es;
-    void* y2 = a + 2 * s.mid_elems * s.es;
-    void* a2 = a + 3 * s.mid_elems * s.es;
-    void* y3 = a + 4 * s.mid_elems * s.es;
-    void* out = a + (4 * s.mid_elems + s.out_elems) * s.es;
+    const ActLayout lay = act_layout(d, s);
+    OFASR_REQUIRE(!lay.fused || (reinterpret_cast<uintptr_t>(act_buf) & 15) == 0, OFASR_ERR_INVALID_ARG,
+                  "%s: act_buf must be 16-byte aligned", name);
+    void* y1 = a + lay.y1 * s.es;
+    void* a1 = a + lay.a1 * s.es;
+    void* y2 = a + lay.y2 * s.es;
+    void* a2 = a + lay.a2 * s.es;
+    void* y3 = a + lay.y3 * s.es;
+    void* out = a + lay.out * s.es;
     float* f = stat_buf + 8 * d->mid + 4 * d->Cout;
 
-    const bool fused = fuse_apply(d, s, act_buf);
+    const bool fused = lay.fused;
     if (!fused && ((d->bn_training[0] && d->num_batches_tracked[0]) || (d->bn_training[1] && d->num_batches_tracked[1]) ||
                    (d->bn_training[2] && d->num_batches_tracked[2]))) {
         OFASR_LAUNCH(bump_counters_kernel, dim3(1), dim3(64), 0, as_stream(stream),
@@ -362,11 +384,14 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     const int64_t HW = d->H * d->W;
     hipStream_t st = as_stream(stream);
     const char* a = (const char*)act_buf;
-    const void* y1 = a;
-    const void* a1 = a + s.mid_elems * s.es;
-    const void* y2 = a + 2 * s.mid_elems * s.es;
-    const void* a2 = a + 3 * s.mid_elems * s.es;
-    const void* y3 = a + 4 * s.mid_elems * s.es;
+    const ActLayout lay = act_layout(d, s);
+    OFASR_REQUIRE(!lay.fused || (reinterpret_cast<uintptr_t>(act_buf) & 15) == 0, OFASR_ERR_INVALID_ARG,
+                  "%s: act_buf must be 16-byte aligned", name);
+    const void* y1 = a + lay.y1 * s.es;
+    const void* a1 = a + lay.a1 * s.es;
+    const void* y2 = a + lay.y2 * s.es;
+    const void* a2 = a + lay.a2 * s.es;
+    const void* y3 = a + lay.y3 * s.es;
     char* t = (char*)tmp_buf;
     void* tA = t;                                    // mid: da2 -> dy2 (in place)
     void* tB = t + s.mid_elems * s.es;               // mid: da1 -> dy1 (in place)
@@ -466,7 +491,7 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
         OFASR_REQUIRE(e1 == hipSuccess, OFASR_ERR_LAUNCH, "%s: stream fork failed: %s", name, hipGetErrorString(e1));
         return OFASR_OK;
     };
-    const bool fused = fuse_apply(d, s, act_buf);
+    const bool fused = lay.fused;
     if (fused)
         OFASR_REQUIRE((reinterpret_cast<uintptr_t>(tmp_buf) & 15) == 0, OFASR_ERR_UNSUPPORTED,
                       "%s: tmp_buf must be 16-byte aligned (the forward pass did not materialise the activations)", name);

@@ -715,7 +715,7 @@ class FusedMBConvFn(Function):
         d = _mbconv_desc(x, cfg, w1, g1, b1, wdw, g2, b2, w2, g3, b3, mats)
         dp = ctypes.byref(d)
         HW = H * W
-        act = torch.empty(N * HW * (4 * mid + 2 * Cout), dtype=x.dtype, device=x.device)
+        act = torch.empty(L.ofasr_mbconv_act_elems(dp), dtype=x.dtype, device=x.device)   # y1 | y2 | y3 | out when fused
         stat = torch.empty(L.ofasr_mbconv_stat_floats(dp), dtype=torch.float32, device=x.device)
         wsn = L.ofasr_mbconv_workspace(dp)
         ws = torch.empty(wsn, dtype=torch.uint8, device=x.device)
@@ -724,7 +724,7 @@ class FusedMBConvFn(Function):
         ctx.save_for_backward(x, act, stat, w1, wdw, w2, g1, g2, g3, *mats)
         ctx.desc = d
         ctx.keep = (bns, ws)       # keeps the BN buffers the descriptor points at alive; workspace reused in backward
-        return act[N * HW * (4 * mid + Cout):].view(N, Cout, H, W)
+        return act[act.numel() - N * HW * Cout:].view(N, Cout, H, W)
 
     @staticmethod
     @once_differentiable
