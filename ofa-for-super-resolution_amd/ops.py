@@ -773,11 +773,12 @@ class FusedMBConvFn(Function):
 # fork/join inside the composite MB-block backward (bandwidth-bound kernels, csrc/mbconv.hip) is 6 % faster.
 SIDE_STREAM = os.environ.get("OFASR_CONV_SIDE_STREAM", "0") != "0"
 # The static convs' weight gradients on the library's side stream, joined with the composite blocks' at the end of the
-# backward pass (needs DEFER_WGRAD).  Off by default: measured 2213 against 2262 images/s with all of them deferred and
-# no change with only the large-plane tail convs (OFASR_CONV_DEFER_MIN_HW) -- the main chain is the critical path
-# (tools/stream_balance.py) and the MFMA weight-gradient kernels slow its kernels down more than they save.
-CONV_DEFER_WGRAD = os.environ.get("OFASR_CONV_DEFER_WGRAD", "0") != "0"
-CONV_DEFER_MIN_HW = int(os.environ.get("OFASR_CONV_DEFER_MIN_HW", "0"))
+# backward pass (needs DEFER_WGRAD).  On for the large-plane decoder convs (H*W >= OFASR_CONV_DEFER_MIN_HW): in round 1
+# this measured 2213 against 2262 images/s -- the side stream was then full of the VALU-bound depthwise weight gradient --
+# and is worth +1.1 % now that it has slack (2439-2445 against 2410-2419, three A/B pairs; all convs deferred: the same).
+# OFASR_CONV_DEFER_WGRAD=0 keeps them on the caller's stream.
+CONV_DEFER_WGRAD = os.environ.get("OFASR_CONV_DEFER_WGRAD", "1") != "0"
+CONV_DEFER_MIN_HW = int(os.environ.get("OFASR_CONV_DEFER_MIN_HW", "10000"))
 _SIDE_STREAMS = {}
 
 
