@@ -1044,10 +1044,13 @@ __device__ __forceinline__ dwm_s16x8 dwg_frag(const char* img, int pos0, int s, 
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <typename T, int K, int WT, bool XF>
+// GBX: the gradient operand is formed from (da, y) through the BN(+ReLU6) backward as it is staged (BwdXf) -- the depthwise
+// input gradient on the chain then does not have to store dy for this kernel (one tensor less written on the chain, one
+// more read here, on the side stream)
+template <typename T, int K, int WT, bool XF, bool GBX = false>
 __global__ void __launch_bounds__(DWG_THREADS) dw_wgrad_mfma_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                     float* __restrict__ df, int N, int C, int H,
-                                                                    InputXf xf) {
+                                                                    InputXf xf, BwdXf bx = BwdXf{}) {
     constexpr int P = K / 2, W = 32 * WT;
     constexpr int AROWS = 64 + 2 * P;
     constexpr int A_BYTES = AROWS * DWG_PITCH * 2, G_BYTES = 64 * DWG_PITCH * 2;
@@ -1061,6 +1064,14 @@ __global__ void __launch_bounds__(DWG_THREADS) dw_wgrad_mfma_kernel(const T* __r
         sc = xf.scale[c];
         be = fmaf(mu, sc, xf.shift[c]);
     }
+    float bmu = 0.f, bsc = 1.f, bxb = 0.f, bka = 0.f, bkbi = 0.f;
+    if constexpr (GBX) {
+        bmu = bx.mean[c];
+        bsc = bx.scale[c];
+        bxb = fmaf(bmu, bsc, bx.shift[c]);
+        bka = bx.ka[c];
+        bkbi = bx.kbi[c];
+    }
     // zero halo rows of both A images (rows [0, P) and [P + H, P + H + P)); the data rows are rewritten per image
     for (int e = tid; e < 2 * 2 * P * (DWG_PITCH / 8); e += DWG_THREADS) {
         const int b = e / (2 * P * (DWG_PITCH / 8)), r2 = (e / (DWG_PITCH / 8)) % (2 * P), q = e % (DWG_PITCH / 8);
@@ -1071,12 +1082,13 @@ __global__ void __launch_bounds__(DWG_THREADS) dw_wgrad_mfma_kernel(const T* __r
     const bool mine = tid < quads;
     const int row = tid / (W / 8), col8 = tid - row * (W / 8);
     const long long plane = (long long)H * W;
-    uint4 ga = make_uint4(0u, 0u, 0u, 0u), gg = ga;
+    uint4 ga = make_uint4(0u, 0u, 0u, 0u), gg = ga, gy = ga;
     auto load = [&](int n) {
         if (mine) {
             const long long off = ((long long)n * C + c) * plane + (long long)row * W + 8 * col8;
             ga = *reinterpret_cast<const uint4*>(x + off);
             gg = *reinterpret_cast<const uint4*>(dy + off);
+            if constexpr (GBX) gy = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(bx.y) + off);
         }
     };
     auto store = [&](int b) {
@@ -1093,8 +1105,25 @@ __global__ void __launch_bounds__(DWG_THREADS) dw_wgrad_mfma_kernel(const T* __r
                 }
                 a = make_uint4(o[0], o[1], o[2], o[3]);
             }
+            uint4 g = gg;
+            if constexpr (GBX) {   // dy = scale*dz - ka - (y - mean)*kbi, dz = da inside the ReLU6 window of BN(y): the arithmetic
+                                   // of dw_mfma_kernel's BX staging, so the weight gradient sees the dy the input gradient saw
+                const uint32_t wv[4] = {gg.x, gg.y, gg.z, gg.w}, yv[4] = {gy.x, gy.y, gy.z, gy.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float d0, d1, y0, y1;
+                    unpack2<T>(wv[i], d0, d1);
+                    unpack2<T>(yv[i], y0, y1);
+                    const float t0 = y0 - bmu, t1 = y1 - bmu;
+                    const float p0 = fmaf(t0, bsc, bxb), p1 = fmaf(t1, bsc, bxb);
+                    const float z0 = (p0 > 0.f && p0 < 6.f) ? d0 : 0.f, z1 = (p1 > 0.f && p1 < 6.f) ? d1 : 0.f;
+                    o[i] = pack2<T>(fmaf(-t0, bkbi, fmaf(bsc, z0, -bka)), fmaf(-t1, bkbi, fmaf(bsc, z1, -bka)));
+                }
+                g = make_uint4(o[0], o[1], o[2], o[3]);
+            }
             *reinterpret_cast<uint4*>(lds[b] + (row + P) * (DWG_PITCH * 2) + col8 * 16) = a;
-            *reinterpret_cast<uint4*>(lds[b] + A_BYTES + row * (DWG_PITCH * 2) + col8 * 16) = gg;
+            *reinterpret_cast<uint4*>(lds[b] + A_BYTES + row * (DWG_PITCH * 2) + col8 * 16) = g;
         }
     };
     dwm_f32x16 acc[WT][WT];
@@ -1276,6 +1305,44 @@ int dwconv_wgrad_xf(const void* dy, const void* x, float* df, int64_t N, int64_t
     hipStream_t st = as_stream(stream);
     if (dtype == OFASR_F16) return launch_wgrad<f16_t, true>(name, dy, x, df, N, C, H, W, K, (float*)workspace, st, xf);
     return launch_wgrad<bf16_t, true>(name, dy, x, df, N, C, H, W, K, (float*)workspace, st, xf);
+}
+
+// weight gradient on the matrix cores with BOTH operands formed on read: a = relu6(BN(x)) (InputXf) and the gradient
+// dy(da, y) through the BN backward (BwdXf).  Only where dw_wgrad_mfma_kernel applies (dwconv_wgrad_bx_supported).
+bool dwconv_wgrad_bx_supported(const void* da, const void* x, const void* y, int64_t N, int64_t C, int64_t H, int64_t W,
+                               int K, int dtype) {
+    static const bool on = [] { const char* e = getenv("OFASR_DW_WGRAD_BX"); return !(e && e[0] == '0'); }();
+    return on && (dtype == OFASR_F16 || dtype == OFASR_BF16) && dw_wgrad_mfma_ok(da, x, N, C, H, W, K, 2) &&
+           (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+}
+
+int dwconv_wgrad_xf_bx(const void* da, const void* x, float* df, int64_t N, int64_t C, int64_t H, int64_t W, int K,
+                       int dtype, InputXf xf, BwdXf bx, void* stream) {
+    const char* name = "dwconv_wgrad_xf_bx";
+    OFASR_REQUIRE(da && x && df, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(xf.scale && xf.shift && xf.mean && bx.y && bx.mean && bx.scale && bx.shift && bx.ka && bx.kbi,
+                  OFASR_ERR_INVALID_ARG, "%s: null transform", name);
+    OFASR_REQUIRE(dwconv_wgrad_bx_supported(da, x, bx.y, N, C, H, W, K, dtype), OFASR_ERR_UNSUPPORTED,
+                  "%s: shape outside the matrix-core weight-gradient kernel", name);
+    hipStream_t st = as_stream(stream);
+    prof_note(2.0 * 3.0 * (double)N * (double)C * (double)H * (double)W + 4.0 * (double)C * K * K,
+              2.0 * K * K * (double)N * (double)C * (double)H * (double)W);
+#define OFASR_DWGB(TT, KK, WT)                                                                                       \
+    OFASR_LAUNCH((dw_wgrad_mfma_kernel<TT, KK, WT, true, true>), dim3((unsigned)C), dim3(DWG_THREADS), 0, st,         \
+                 (const TT*)da, (const TT*)x, df, (int)N, (int)C, (int)H, xf, bx)
+#define OFASR_DWGB_T(TT)                                                                                             \
+    do {                                                                                                            \
+        if (W == 64) {                                                                                              \
+            if (K == 7) OFASR_DWGB(TT, 7, 2); else if (K == 5) OFASR_DWGB(TT, 5, 2); else OFASR_DWGB(TT, 3, 2);       \
+        } else {                                                                                                    \
+            if (K == 7) OFASR_DWGB(TT, 7, 1); else if (K == 5) OFASR_DWGB(TT, 5, 1); else OFASR_DWGB(TT, 3, 1);       \
+        }                                                                                                           \
+    } while (0)
+    if (dtype == OFASR_F16) OFASR_DWGB_T(f16_t);
+    else OFASR_DWGB_T(bf16_t);
+#undef OFASR_DWGB_T
+#undef OFASR_DWGB
+    return check_launch(name);
 }
 
 // input gradient of the depthwise conv with the gradient operand read through the BN(+ReLU6) backward (BwdXf):

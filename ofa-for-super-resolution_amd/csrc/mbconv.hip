@@ -17,6 +17,10 @@
 namespace ofasr {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static bool bn_fold_enabled() {
+    static const bool on = [] { const char* e = getenv("OFASR_MBCONV_BN_BWD_FOLD"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static std::atomic<int> g_bn_bwd_stat{[] { const char* e = getenv("OFASR_MBCONV_BN_BWD_STAT"); return (e && e[0] == '1') ? 1 : 0; }()};
 
 struct MbSizes {
@@ -516,11 +520,15 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     // stream.  Per BN the chain loses a pass ("read da, read y, write dy"), a launch and one tensor of traffic.  (Reading
     // (da, y) in the weight-gradient kernels too, instead of the stored dy, was measured slower: 2122 against 2261 img/s --
     // those kernels bound the side stream, which then bounds the step.)
-    static const bool bn_fold = [] { const char* e = getenv("OFASR_MBCONV_BN_BWD_FOLD"); return !(e && e[0] == '0'); }();
+    const bool bn_fold = bn_fold_enabled();
     float* coef = reinterpret_cast<float*>((char*)workspace + s.coef_off);
     void* tC = t + (2 * s.mid_elems + (size_t)d->N * d->Cout * HW) * s.es;   // mid: dy2, left there by the depthwise dgrad
-    const BwdXf bx2{y2, s2.mean, s2.scale, s2.shift, coef, coef + d->mid, tC};
-    const BwdXf bx1{y1, s1.mean, s1.scale, s1.shift, coef + 2 * d->mid, coef + 3 * d->mid, tA};   // dy1 over the dead da2
+    // Where the depthwise weight gradient runs on the matrix cores it forms dy2 from (da2, y2) itself (side stream), so the
+    // depthwise input gradient stores no dy2: tA keeps da2 for that kernel and dy1 goes to tC instead of over the dead da2.
+    const bool wg_bx = fused && bn_fold_enabled() &&
+                       dwconv_wgrad_bx_supported(tA, y1, y2, d->N, d->mid, d->H, d->W, d->K, d->dtype);
+    const BwdXf bx2{y2, s2.mean, s2.scale, s2.shift, coef, coef + d->mid, wg_bx ? nullptr : tC};
+    const BwdXf bx1{y1, s1.mean, s1.scale, s1.shift, coef + 2 * d->mid, coef + 3 * d->mid, wg_bx ? tC : tA};
     const bool bxp = fused && bn_fold && dwconv_xf_supported(tA, tB, d->H, d->W, d->K, d->dtype) &&
                      (reinterpret_cast<uintptr_t>(tC) & 15) == 0 &&
                      pwconv_dgrad_bx_supported(tB, y1, dx, d->residual ? dout : nullptr, d->w1, d->ldw1, d->Cin, d->mid, HW,
@@ -553,10 +561,14 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
         }
         rc = dwconv_dgrad_bx(tA, f, tB, d->N, d->mid, d->H, d->W, d->K, d->dtype, bx2, stream);   // also leaves dy2 in tC
         if (rc) return rc;
-        rc = fork(1);   // dy2 (tC) is final
+        rc = fork(1);   // dy2 (tC), or what the weight gradient forms it from (da2 in tA, the BN2 coefficients), is final
         if (rc) return rc;
-        rc = dwconv_wgrad_xf(tC, y1, dfp, d->N, d->mid, d->H, d->W, d->K, d->dtype, xf_of(stat_buf, 0, d->mid, d->Cout),
-                             side_ws, s.side, sst);
+        if (wg_bx)
+            rc = dwconv_wgrad_xf_bx(tA, y1, dfp, d->N, d->mid, d->H, d->W, d->K, d->dtype, xf_of(stat_buf, 0, d->mid, d->Cout),
+                                    BwdXf{y2, s2.mean, s2.scale, s2.shift, coef, coef + d->mid, nullptr}, sst);
+        else
+            rc = dwconv_wgrad_xf(tC, y1, dfp, d->N, d->mid, d->H, d->W, d->K, d->dtype, xf_of(stat_buf, 0, d->mid, d->Cout),
+                                 side_ws, s.side, sst);
         if (rc) return rc;
         rc = ofasr_ktransform_bwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, dfp, g->dwdw_max, g->dmats,
                                   d->mid, kt_ws, s.ws_kt + 256, sst);
@@ -569,9 +581,9 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
         rc = pwconv_dgrad_add_bx(tB, d->w1, d->ldw1, dx, d->residual ? dout : nullptr, d->N, d->Cin, d->mid, HW, d->dtype, bx1,
                                  stream);
         if (rc) return rc;
-        rc = fork(2);   // dy1 (tA) is final
+        rc = fork(2);   // dy1 is final
         if (rc) return rc;
-        rc = ofasr_pwconv_wgrad(tA, x, g->dw1, d->ldw1, d->N, d->Cin, d->mid, HW, d->dtype, side_ws, s.side, sst);
+        rc = ofasr_pwconv_wgrad(wg_bx ? tC : tA, x, g->dw1, d->ldw1, d->N, d->Cin, d->mid, HW, d->dtype, side_ws, s.side, sst);
         if (rc) return rc;
     } else {
     // BN2 + ReLU6 (in place: da2 -> dy2)

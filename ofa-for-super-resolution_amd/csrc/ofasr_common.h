@@ -268,6 +268,10 @@ int dwconv_fwd_xf(const void* x, const float* f, void* y, int64_t N, int64_t C, 
                   InputXf xf, void* stream, StatOut so = StatOut{nullptr, 0}, BnFold fold = BnFold{});
 int dwconv_wgrad_xf(const void* dy, const void* x, float* df, int64_t N, int64_t C, int64_t H, int64_t W, int K,
                     int dtype, InputXf xf, void* workspace, size_t workspace_bytes, void* stream);
+bool dwconv_wgrad_bx_supported(const void* da, const void* x, const void* y, int64_t N, int64_t C, int64_t H, int64_t W,
+                               int K, int dtype);
+int dwconv_wgrad_xf_bx(const void* da, const void* x, float* df, int64_t N, int64_t C, int64_t H, int64_t W, int K,
+                       int dtype, InputXf xf, BwdXf bx, void* stream);
 int dwconv_dgrad_bx(const void* da, const float* f, void* dx, int64_t N, int64_t C, int64_t H, int64_t W, int K,
                     int dtype, BwdXf bx, void* stream);
 // ofasr_bn_finalize that also bumps up to three num_batches_tracked counters (thread 0)

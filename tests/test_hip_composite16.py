@@ -158,7 +158,7 @@ def test_composite_block_16bit_vs_oracle(ora, case, bstat):
         assert ran(bwd_table, "pw_wgrad_direct_kernel<%s, 1>" % T) + ran(bwd_table, "pw_wgrad_direct_kernel<%s, 2>" % T) == 1
         assert ran(bwd_table, "pw_wgrad_direct_kernel<%s, 0>" % T) == 1, bwd_table
         if Ww in (32, 64) and Hh % 16 == 0 and Hh <= 64:   # depthwise weight gradient on the matrix cores, no reduce launch
-            assert ran(bwd_table, "dw_wgrad_mfma_kernel<%s, %d, %d, true>" % (T, K, Ww // 32)) == 1, bwd_table
+            assert ran(bwd_table, "dw_wgrad_mfma_kernel<%s, %d, %d, true, true>" % (T, K, Ww // 32)) == 1, bwd_table
             assert ran(bwd_table, "dw_wgrad_vec") == 0, bwd_table
         else:
             assert ran(bwd_table, "dw_wgrad_vec_kernel<%s, %d, true>" % (T, K)) == 1, bwd_table
@@ -253,15 +253,23 @@ def test_composite_block_16bit_vs_oracle(ora, case, bstat):
     margin = 4 * RT[dtype] * 0.02
     safe2, safe1 = c16.edge_safe(pre2, margin), c16.edge_safe(pre1, margin)
     d2, dg2, db2 = c16.bn_bwd(c16.r16(da2, dtype), y2, m2, i2, bnp[1]["weight"], pre2, True, train)
-    dy2_gpu = tC if folded_bwd else tA
-    close16(dy2_gpu, c16.r16(d2, dtype), dtype, "dy2 (project dgrad + BN2 backward)", safe2, 3e-4)
+    # where the depthwise weight gradient runs on the matrix cores with both operands formed on read (dw_wgrad_mfma_kernel
+    # <..., true, true>) dy2 is stored nowhere: tA keeps da2 for that kernel, dy1 goes to tC
+    wg_bx = any("dw_wgrad_mfma_kernel" in k and k.rstrip().endswith("true, true>") for k in bwd_table)
+    if wg_bx:
+        close16(tA, c16.r16(da2, dtype), dtype, "da2 (project dgrad, kept for the depthwise weight gradient)")
+        d2g, _, _ = c16.bn_bwd(tA, y2, m2, i2, bnp[1]["weight"], pre2, True, train)
+        dy2_gpu = c16.r16(d2g, dtype)          # dy2 as both depthwise kernels form it from the stored (da2, y2)
+    else:
+        dy2_gpu = tC if folded_bwd else tA
+        close16(dy2_gpu, c16.r16(d2, dtype), dtype, "dy2 (project dgrad + BN2 backward)", safe2, 3e-4)
     sc = float(np.abs(da2).sum(axis=(0, 2, 3)).max())
     assert np.abs(grads[pfx + "depth_conv.bn.bn.weight"][:mid] - dg2).max() <= 2e-4 * sc * 3
     assert np.abs(grads[pfx + "depth_conv.bn.bn.bias"][:mid] - db2).max() <= 2e-4 * sc
     a1_in = c16.r16(a1, dtype) if dw_mma else a1.astype(np.float32)
     # the depthwise input gradient convolves the dy2 it forms itself: the stored 16-bit value on the matrix cores, the
     # fp32 value in the vector kernel (folded path); after an apply pass it reads the stored tensor
-    dy2_in = d2.astype(np.float32) if (folded_bwd and not dw_mma) else dy2_gpu
+    dy2_in = (d2g if wg_bx else d2).astype(np.float32) if (folded_bwd and not dw_mma) else dy2_gpu
     da1, _ = ora.dwconv_bwd(dy2_in, a1_in, c16.r16(f_gpu, dtype) if dw_mma else f_gpu)
     # the weight-gradient kernel on the matrix cores sees the activated operand rounded to 16 bits; the vector kernel reads
     # it in fp32
@@ -282,8 +290,8 @@ def test_composite_block_16bit_vs_oracle(ora, case, bstat):
             near = ora.dwconv_fwd((~safe2).astype(np.float32), np.ones((mid, 1, K, K), np.float32)) > 0
         close16(tB, c16.r16(da1, dtype), dtype, "da1 (depthwise dgrad of the folded BN2 backward)", ~near, 3e-4)
         d1, dg1, db1 = c16.bn_bwd(tB, y1, m1, i1, bnp[0]["weight"], pre1, True, train)
-        close16(tA, c16.r16(d1, dtype), dtype, "dy1 (BN1 backward, stored by the expand dgrad)", safe1, 3e-4)
-        dy1_gpu = tA
+        dy1_gpu = tC if wg_bx else tA
+        close16(dy1_gpu, c16.r16(d1, dtype), dtype, "dy1 (BN1 backward, stored by the expand dgrad)", safe1, 3e-4)
     else:
         d1, dg1, db1 = c16.bn_bwd(c16.r16(da1, dtype), y1, m1, i1, bnp[0]["weight"], pre1, True, train)
         close16(tB, c16.r16(d1, dtype), dtype, "dy1 (depthwise dgrad + BN1 backward)", safe1, 3e-4)
