@@ -889,6 +889,34 @@ int bn_bwd_reduce_coef(const void* dy, const void* x, const float* scale, const 
                  (double)N * (double)HW, training, scale, invstd, dgamma, dbeta, ka, kbi);
     return check_launch(name);
 }
+int bn_bwd_reduce_only(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
+                       const float* invstd, int64_t N, int64_t C, int64_t HW, int act, int dtype, void* workspace,
+                       size_t workspace_bytes, int* P_out, void* stream) {
+    const char* name = "bn_bwd_reduce_only";
+    int rc = check_bn(name, N, C, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(dy && x && scale && shift && mean && invstd && P_out, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    const int P = bn_parts(N, C);
+    const size_t need = (size_t)P * C * 2 * sizeof(double);
+    OFASR_REQUIRE(workspace && workspace_bytes >= need, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", name,
+                  workspace_bytes, need);
+    double* partial = (double*)workspace;
+    dim3 grid((unsigned)C, (unsigned)P);
+    hipStream_t st = as_stream(stream);
+    const bool v = vec_ok(HW, dtype, dy, x, nullptr, nullptr);
+    const void* residual = nullptr;
+    prof_note((dtype == OFASR_F32 ? 4.0 : 2.0) * (double)N * (double)C * (double)HW * 2.0, 0.0);
+#define OFASR_BNR2(VEC, ACT)                                                                                           \
+    OFASR_LAUNCH((bn_bwd_reduce_kernel<T, VEC, ACT, false>), grid, dim3(BN_THREADS), 0, st, (const T*)dy, (const T*)x, \
+                 (const T*)residual, scale, shift, mean, invstd, partial, (int)N, (int)C, (int)HW, P)
+    OFASR_BN_DISPATCH_T(dtype, {
+        if (v) { if (act == 1) OFASR_BNR2(true, 1); else OFASR_BNR2(true, 0); }
+        else { if (act == 1) OFASR_BNR2(false, 1); else OFASR_BNR2(false, 0); }
+    });
+#undef OFASR_BNR2
+    *P_out = P;
+    return check_launch(name);
+}
 }  // namespace ofasr
 
 OFASR_EXPORT size_t ofasr_bn_act_bwd_workspace(int64_t N, int64_t C) {

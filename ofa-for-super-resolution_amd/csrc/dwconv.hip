@@ -433,8 +433,11 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_mfma_kernel(const T* __restr
         bmu = bx.mean[c];
         bsc = bx.scale[c];
         bxb = fmaf(bmu, bsc, bx.shift[c]);
-        bka = bx.ka[c];
-        bkbi = bx.kbi[c];
+        if (bx.fold_partial) bwdxf_fold(bx, c, bsc, n0 == 0 && lane == 0, bka, bkbi);   // wave-uniform; image group 0 publishes
+        else {
+            bka = bx.ka[c];
+            bkbi = bx.kbi[c];
+        }
     }
 
     int abase[2][3];   // byte offset of this lane's fragment chunk for (column block, chunk pair), row r
@@ -619,8 +622,11 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_vec_kernel(const T* __restri
         bmu = bx.mean[c];
         bsc = bx.scale[c];
         bxb = fmaf(bmu, bsc, bx.shift[c]);
-        bka = bx.ka[c];
-        bkbi = bx.kbi[c];
+        if (bx.fold_partial) bwdxf_fold(bx, c, bsc, plane < C && slab == 0 && lane == 0, bka, bkbi);   // wave-uniform
+        else {
+            bka = bx.ka[c];
+            bkbi = bx.kbi[c];
+        }
     }
     float xsc = 1.f, xmu = 0.f, xb = 0.f;            // fused BN + ReLU6 of the input plane (wave-uniform)
     if constexpr (XF) {
@@ -1352,7 +1358,9 @@ int dwconv_dgrad_bx(const void* da, const float* f, void* dx, int64_t N, int64_t
     const char* name = "dwconv_dgrad_bx";
     int rc = check_conv_args(name, da, f, dx, N, C, H, W, K, dtype);
     if (rc) return rc;
-    OFASR_REQUIRE(bx.y && bx.mean && bx.scale && bx.shift && bx.ka && bx.kbi, OFASR_ERR_INVALID_ARG, "%s: null transform", name);
+    OFASR_REQUIRE(bx.y && bx.mean && bx.scale && bx.shift &&
+                      ((bx.ka && bx.kbi) || (bx.fold_partial && bx.fold_invstd && bx.fold_P > 0 && bx.fold_C == C)),
+                  OFASR_ERR_INVALID_ARG, "%s: null transform", name);
     OFASR_REQUIRE(dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_UNSUPPORTED, "%s: 16-bit only", name);
     OFASR_REQUIRE(((reinterpret_cast<uintptr_t>(bx.y) | reinterpret_cast<uintptr_t>(bx.dy_out)) & 15) == 0,
                   OFASR_ERR_UNSUPPORTED, "%s: unaligned y / dy_out", name);

@@ -527,8 +527,24 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     // depthwise input gradient stores no dy2: tA keeps da2 for that kernel and dy1 goes to tC instead of over the dead da2.
     const bool wg_bx = fused && bn_fold_enabled() &&
                        dwconv_wgrad_bx_supported(tA, y1, y2, d->N, d->mid, d->H, d->W, d->K, d->dtype);
-    const BwdXf bx2{y2, s2.mean, s2.scale, s2.shift, coef, coef + d->mid, wg_bx ? nullptr : tC};
-    const BwdXf bx1{y1, s1.mean, s1.scale, s1.shift, coef + 2 * d->mid, coef + 3 * d->mid, wg_bx ? tC : tA};
+    BwdXf bx2{y2, s2.mean, s2.scale, s2.shift, coef, coef + d->mid, wg_bx ? nullptr : tC};
+    BwdXf bx1{y1, s1.mean, s1.scale, s1.shift, coef + 2 * d->mid, coef + 3 * d->mid, wg_bx ? tC : tA};
+    // The consumers fold the reduction pass's partial slabs themselves (BwdXf::fold_*): no coefficient launch between a
+    // reduction and its consumer on the chain (2 x 5.7 us of pure latency per block); the depthwise input gradient also
+    // publishes (ka2, kbi2) for the side stream's weight gradient.  OFASR_MBCONV_BN_COEF_FOLD=0: the coefficient kernel.
+    static const bool coef_fold = [] { const char* e = getenv("OFASR_MBCONV_BN_COEF_FOLD"); return !(e && e[0] == '0'); }();
+    auto arm_fold = [&](BwdXf& bx, int P, const StatView& sv, int which) {
+        bx.fold_partial = (const double*)workspace;
+        bx.fold_P = P;
+        bx.fold_C = (int)d->mid;
+        bx.fold_training = d->bn_training[which];
+        bx.fold_M = (double)d->N * (double)HW;
+        bx.fold_invstd = sv.invstd;
+        bx.fold_dgamma = g->dgamma[which];
+        bx.fold_dbeta = g->dbeta[which];
+        bx.coef_ka = const_cast<float*>(bx.ka);
+        bx.coef_kbi = const_cast<float*>(bx.kbi);
+    };
     const bool bxp = fused && bn_fold && dwconv_xf_supported(tA, tB, d->H, d->W, d->K, d->dtype) &&
                      (reinterpret_cast<uintptr_t>(tC) & 15) == 0 &&
                      pwconv_dgrad_bx_supported(tB, y1, dx, d->residual ? dout : nullptr, d->w1, d->ldw1, d->Cin, d->mid, HW,
@@ -553,7 +569,13 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     }
     if (rc) return rc;
     if (bxp) {
-        if (!st2) {
+        if (!st2 && coef_fold) {
+            int P2 = 0;
+            rc = bn_bwd_reduce_only(tA, y2, s2.scale, s2.shift, s2.mean, s2.invstd, d->N, d->mid, HW, 1, d->dtype, workspace,
+                                    s.scratch, &P2, stream);
+            if (rc) return rc;
+            arm_fold(bx2, P2, s2, 1);
+        } else if (!st2) {
             rc = bn_bwd_reduce_coef(tA, y2, s2.scale, s2.shift, s2.mean, s2.invstd, g->dgamma[1], g->dbeta[1], coef,
                                     coef + d->mid, d->N, d->mid, HW, 1, d->bn_training[1], d->dtype, workspace, s.scratch,
                                     stream);
@@ -573,9 +595,17 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
         rc = ofasr_ktransform_bwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, dfp, g->dwdw_max, g->dmats,
                                   d->mid, kt_ws, s.ws_kt + 256, sst);
         if (rc) return rc;
-        rc = bn_bwd_reduce_coef(tB, y1, s1.scale, s1.shift, s1.mean, s1.invstd, g->dgamma[0], g->dbeta[0], coef + 2 * d->mid,
-                                coef + 3 * d->mid, d->N, d->mid, HW, 1, d->bn_training[0], d->dtype, workspace, s.scratch,
-                                stream);
+        if (coef_fold) {
+            int P1 = 0;
+            rc = bn_bwd_reduce_only(tB, y1, s1.scale, s1.shift, s1.mean, s1.invstd, d->N, d->mid, HW, 1, d->dtype, workspace,
+                                    s.scratch, &P1, stream);
+            if (rc) return rc;
+            arm_fold(bx1, P1, s1, 0);
+        } else {
+            rc = bn_bwd_reduce_coef(tB, y1, s1.scale, s1.shift, s1.mean, s1.invstd, g->dgamma[0], g->dbeta[0], coef + 2 * d->mid,
+                                    coef + 3 * d->mid, d->N, d->mid, HW, 1, d->bn_training[0], d->dtype, workspace, s.scratch,
+                                    stream);
+        }
         if (rc) return rc;
         // expand input gradient (+ the shortcut's dout); leaves dy1 in tA (da2 there is dead: its one reader ran above)
         rc = pwconv_dgrad_add_bx(tB, d->w1, d->ldw1, dx, d->residual ? dout : nullptr, d->N, d->Cin, d->mid, HW, d->dtype, bx1,

@@ -155,7 +155,48 @@ struct BwdXf {
     const float* ka;
     const float* kbi;
     void* dy_out;         // where the consumer leaves dy (same shape / element type), or nullptr
+    // Optional: the consumer folds the reduction pass's partial slabs itself (no coefficient launch between the two).
+    // fold_partial[(q * C + c) * 2 + {0, 1}] = (sum dz, sum dz * xhat) of part q < fold_P (bn_bwd_reduce_kernel's layout),
+    // folded in fp64 in the order q = 0 .. fold_P-1 exactly as bn_bwd_coef_kernel does; ka / kbi above are then ignored.
+    // ONE designated unit per channel also writes dgamma / dbeta and (coef_ka, coef_kbi) -- the latter for a later kernel
+    // that takes finished coefficients (the side stream's weight gradient).
+    const double* fold_partial;
+    int fold_P, fold_C, fold_training;
+    double fold_M;
+    const float* fold_invstd;
+    float* fold_dgamma;
+    float* fold_dbeta;
+    float* coef_ka;
+    float* coef_kbi;
 };
+#if defined(__HIPCC__)
+// (ka, kbi) of channel c from the partial slabs; `writer`: this unit also publishes dgamma / dbeta / the coefficients
+__device__ __forceinline__ void bwdxf_fold(const BwdXf& bx, int c, float sc, bool writer, float& ka, float& kbi) {
+    double s = 0.0, sx = 0.0;
+    for (int q0 = 0; q0 < bx.fold_P; q0 += 8) {      // the loads of a round requested together, summed in order
+        double a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = q0 + j < bx.fold_P ? q0 + j : bx.fold_P - 1;
+            a[j] = bx.fold_partial[((long long)q * bx.fold_C + c) * 2];
+            b[j] = bx.fold_partial[((long long)q * bx.fold_C + c) * 2 + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s += q0 + j < bx.fold_P ? a[j] : 0.0;
+            sx += q0 + j < bx.fold_P ? b[j] : 0.0;
+        }
+    }
+    ka = bx.fold_training ? (float)((double)sc * (s / bx.fold_M)) : 0.f;
+    kbi = bx.fold_training ? (float)((double)sc * (double)bx.fold_invstd[c] * (sx / bx.fold_M)) : 0.f;
+    if (writer) {
+        if (bx.fold_dgamma) bx.fold_dgamma[c] = (float)sx;
+        if (bx.fold_dbeta) bx.fold_dbeta[c] = (float)s;
+        if (bx.coef_ka) bx.coef_ka[c] = ka;
+        if (bx.coef_kbi) bx.coef_kbi[c] = kbi;
+    }
+}
+#endif
 // The REDUCTION pass of the same backward folded into the kernel that produces da (the gradient of the activated
 // tensor): the producer reads y at the positions it writes and leaves, per channel c and producer unit p (a pixel tile,
 // a plane slab), partial[c * P + p] = (sum dz, sum dz * (y - mean)) with dz as above and da as stored; bn_bwd_coef_cp
@@ -181,6 +222,11 @@ int bn_bwd_reduce_coef(const void* dy, const void* x, const float* scale, const 
                        const float* invstd, float* dgamma, float* dbeta, float* ka, float* kbi, int64_t N, int64_t C,
                        int64_t HW, int act, int training, int dtype, void* workspace, size_t workspace_bytes,
                        void* stream);
+// only the reduction pass: the partial slabs stay in `workspace` ([P][C][2] doubles, *P_out parts) for a consumer that
+// folds them itself (BwdXf::fold_partial)
+int bn_bwd_reduce_only(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
+                       const float* invstd, int64_t N, int64_t C, int64_t HW, int act, int dtype, void* workspace,
+                       size_t workspace_bytes, int* P_out, void* stream);
 
 // A consumer kernel can fold the producer's epilogue partials itself (no finalize launch between the two): every
 // block derives scale / mean / beta of the channels it reads from partial[c * P + 0..P) in fp64 in a fixed order, and

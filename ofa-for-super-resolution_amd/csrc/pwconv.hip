@@ -826,8 +826,15 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __re
             bxt[ch] = mu;
             bxt[FOLD_KMAX + ch] = sc;
             bxt[2 * FOLD_KMAX + ch] = fmaf(mu, sc, bx.shift[ch]);
-            bxt[3 * FOLD_KMAX + ch] = bx.ka[ch];
-            bxt[4 * FOLD_KMAX + ch] = bx.kbi[ch];
+            if (bx.fold_partial) {   // workgroup-uniform: fold the reduction pass's partial slabs here; block (0, 0) publishes
+                float ka, kbi;
+                bwdxf_fold(bx, ch, sc, blockIdx.x == 0 && blockIdx.y == 0, ka, kbi);
+                bxt[3 * FOLD_KMAX + ch] = ka;
+                bxt[4 * FOLD_KMAX + ch] = kbi;
+            } else {
+                bxt[3 * FOLD_KMAX + ch] = bx.ka[ch];
+                bxt[4 * FOLD_KMAX + ch] = bx.kbi[ch];
+            }
         }
         __syncthreads();
     }
@@ -1589,7 +1596,9 @@ int pwconv_dgrad_add_bx(const void* da, const float* w, int64_t ldw, void* dx, c
     const char* name = "pwconv_dgrad_add_bx";
     int rc = check_pw_args(name, da, w, dx, ldw, N, Cin, Cout, HW, dtype);
     if (rc) return rc;
-    OFASR_REQUIRE(bx.y && bx.mean && bx.scale && bx.shift && bx.ka && bx.kbi, OFASR_ERR_INVALID_ARG, "%s: null transform", name);
+    OFASR_REQUIRE(bx.y && bx.mean && bx.scale && bx.shift &&
+                      ((bx.ka && bx.kbi) || (bx.fold_partial && bx.fold_invstd && bx.fold_P > 0 && bx.fold_C == Cout)),
+                  OFASR_ERR_INVALID_ARG, "%s: null transform", name);
     OFASR_REQUIRE(pwconv_dgrad_bx_supported(da, bx.y, dx, addend, w, ldw, Cin, Cout, HW, dtype), OFASR_ERR_UNSUPPORTED,
                   "%s: needs the pipelined fan-in kernel (aligned 16-bit tensors, 64 < Cout <= %d)", name, FOLD_KMAX);
     if (N * HW == 0) return OFASR_OK;

@@ -164,14 +164,15 @@ def test_composite_block_16bit_vs_oracle(ora, case, bstat):
             assert ran(bwd_table, "dw_wgrad_vec_kernel<%s, %d, true>" % (T, K)) == 1, bwd_table
         nstat = ran(bwd_table, "bn_bwd_coef_cp_kernel")
         assert ran(bwd_table, "bn_bwd_reduce_kernel") == 3 - nstat and ran(bwd_table, "bn_bwd_apply_kernel") == 1
-        assert ran(bwd_table, "bn_bwd_coef_kernel") == 2 - nstat
+        # ... and no coefficient launch either: the consumers fold the reduction's partial slabs themselves (BwdXf::fold_*)
+        assert ran(bwd_table, "bn_bwd_coef_kernel") == 0
         if K in (5, 7) and Ww in (32, 64):
             assert ran(fwd_table, "dw_mfma_kernel<%s, %d, false, true, true, false>" % (T, K)) == 1, fwd_table
             assert ran(bwd_table, "dw_mfma_kernel<%s, %d, true, false, false, true>" % (T, K)) == 1, bwd_table
         else:
             assert ran(fwd_table, "dw_vec_kernel<%s, %d, false, true, true, false>" % (T, K)) == 1, fwd_table
             assert ran(bwd_table, "dw_vec_kernel<%s, %d, true, false, false, true>" % (T, K)) == 1, bwd_table
-    folded_bwd = ran(bwd_table, "bn_bwd_coef_kernel") + ran(bwd_table, "bn_bwd_coef_cp_kernel") == 2
+    folded_bwd = ran(bwd_table, "bn_bwd_apply_kernel") == 1     # only BN3 has an apply pass
     dw_mma = ran(fwd_table, "dw_mfma_kernel") > 0
     assert ran(fwd_table, "bn_stats_kernel") == 0 and ran(fwd_table, "bn_finalize") == 0 or not (train and aligned)
 
