@@ -290,6 +290,12 @@ int ofasr_bn_finalize_cp(const void* partial, int64_t P, int64_t C, double count
                          void* stream);
 int ofasr_pixel_shuffle2_bn(const void* x, void* y, const float* stats, int64_t N, int64_t C, int64_t H, int64_t W,
                             int dtype, void* stream);
+/* ... and its backward: dout arrives in the SHUFFLED layout [N, C/4, 2H, 2W]; both BatchNorm-backward passes read it
+ * through the inverse shuffle (no un-shuffle pass).  dx [N, C, H, W], dgamma / dbeta [C]; act none, no residual. */
+size_t ofasr_bn_bwd_ps2_workspace(int64_t N, int64_t C);
+int ofasr_bn_bwd_ps2(const void* dout, const void* x, void* dx, const float* scale, const float* mean, const float* invstd,
+                     float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t H, int64_t W, int training, int dtype,
+                     void* workspace, size_t workspace_bytes, void* stream);
 /* Inference form of a whole ConvLayer (reference ofa/layers.py:120-151 in eval mode; the decoder's conv -> BN ->
  * PixelShuffle(2) stages, ofa_mbs4.py:111-123): y = act(BN_eval(conv(x))) as ONE kernel -- the BatchNorm's affine map
  * (scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale) is applied to the fp32 accumulators

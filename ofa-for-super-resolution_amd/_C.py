@@ -69,6 +69,9 @@ SIGNATURES = {
     "ofasr_bn_finalize_cp": (_c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_double,
                                       ctypes.c_double, _c_int, _c_vp, _c_vp]),
     "ofasr_pixel_shuffle2_bn": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_vp]),
+    "ofasr_bn_bwd_ps2_workspace": (_c_sz, [_c_i64, _c_i64]),
+    "ofasr_bn_bwd_ps2": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
+                                  _c_int, _c_vp, _c_sz, _c_vp]),
     "ofasr_conv2d_infer_operand_bytes": (_c_sz, [_c_i64, _c_i64, _c_int]),
     "ofasr_conv2d_infer_prepare": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_double, _c_i64, _c_i64, _c_int, _c_int,
                                             _c_vp, _c_sz, _c_vp]),

@@ -515,6 +515,124 @@ __global__ void __launch_bounds__(64) bn_bwd_coef_cp_kernel(const float2* __rest
     }
 }
 
+// ------------------------------------------------------------------- BN backward through PixelShuffle(2)
+// ConvLayer with act_func "pixelshuffle" (conv -> BN -> PixelShuffle(2), reference ofa/layers.py:120-151): the incoming
+// gradient arrives in the shuffled layout dout[N, C/4, 2H, 2W]; dz[n, 4g + j, h, w] = dout[n, g, 2h + (j >> 1), 2w + (j & 1)].
+// Both passes read it THROUGH the inverse shuffle (two 32-byte runs of two up-sampled rows = the same 8 pixels of the four
+// channels of group g) instead of a separate un-shuffle pass that writes and re-reads the whole tensor.  16-bit tensors, no
+// activation (the shuffle is the layer's activation), W % 8 == 0.  One block = one channel group x images p, p+P, ..
+__device__ __forceinline__ uint32_t bnps_lo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }
+__device__ __forceinline__ uint32_t bnps_hi(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }
+__device__ __forceinline__ void bnps_unzip(const uint4& lo, const uint4& hi, uint4& a, uint4& b) {
+    a = make_uint4(bnps_lo(lo.x, lo.y), bnps_lo(lo.z, lo.w), bnps_lo(hi.x, hi.y), bnps_lo(hi.z, hi.w));
+    b = make_uint4(bnps_hi(lo.x, lo.y), bnps_hi(lo.z, lo.w), bnps_hi(hi.x, hi.y), bnps_hi(hi.z, hi.w));
+}
+// the four channels' 8-pixel pieces of item (h, wq) of group plane `gp` (= n * C/4 + g) from the shuffled tensor
+__device__ __forceinline__ void bnps_load(const uint4* __restrict__ dout, long long gp, int h, int wq, int H, int Wq,
+                                          uint4 (&dz)[4]) {
+    const long long hr0 = gp * 4 * (long long)H * Wq + (long long)(2 * h) * (2 * Wq) + 2 * wq;
+    const uint4 lo0 = dout[hr0], hi0 = dout[hr0 + 1], lo1 = dout[hr0 + 2 * Wq], hi1 = dout[hr0 + 2 * Wq + 1];
+    bnps_unzip(lo0, hi0, dz[0], dz[1]);
+    bnps_unzip(lo1, hi1, dz[2], dz[3]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BN_THREADS) bn_bwd_reduce_ps_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ x,
+                                                                      const float* __restrict__ mean,
+                                                                      const float* __restrict__ invstd,
+                                                                      double* __restrict__ partial, int N, int C, int H,
+                                                                      int Wq, int P) {
+    const int g = blockIdx.x, p = blockIdx.y, G = C / 4;
+    float mu[4], is[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mu[j] = mean[4 * g + j];
+        is[j] = invstd[4 * g + j];
+    }
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, sx[4] = {0.0, 0.0, 0.0, 0.0};
+    const int items = H * Wq;
+    const long long plane = (long long)H * Wq;
+    for (int n = p; n < N; n += P) {
+        for (int it = threadIdx.x; it < items; it += BN_THREADS) {
+            const int h = it / Wq, wq = it - h * Wq;
+            uint4 dz[4];
+            bnps_load(dout, (long long)n * G + g, h, wq, H, Wq, dz);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float f[8], gd[8];
+                unpack16<T>(x[((long long)n * C + 4 * g + j) * plane + it], f);
+                unpack16<T>(dz[j], gd);
+                float s8 = 0.f, q8 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s8 += gd[e];
+                    q8 = fmaf(gd[e], (f[e] - mu[j]) * is[j], q8);
+                }
+                s[j] += (double)s8;
+                sx[j] += (double)q8;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        block_reduce2(s[j], sx[j]);
+        if (threadIdx.x == 0) {
+            partial[((long long)p * C + 4 * g + j) * 2] = s[j];
+            partial[((long long)p * C + 4 * g + j) * 2 + 1] = sx[j];
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BN_THREADS) bn_bwd_apply_ps_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ x,
+                                                                     uint4* __restrict__ dx, const float* __restrict__ scale,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd,
+                                                                     const double* __restrict__ partial, int Pred, double M,
+                                                                     int training, float* __restrict__ dgamma,
+                                                                     float* __restrict__ dbeta, int N, int C, int H, int Wq,
+                                                                     int P) {
+    const int g = blockIdx.x, p = blockIdx.y, G = C / 4;
+    float k1[4], mu[4], is[4], ka[4], kb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * g + j;
+        double s = 0.0, sx = 0.0;
+        for (int q = 0; q < Pred; ++q) {      // Pred <= 16: fixed order, as bn_bwd_apply_kernel
+            s += partial[((long long)q * C + c) * 2];
+            sx += partial[((long long)q * C + c) * 2 + 1];
+        }
+        if (p == 0 && threadIdx.x == 0) {
+            if (dgamma) dgamma[c] = (float)sx;
+            if (dbeta) dbeta[c] = (float)s;
+        }
+        k1[j] = scale[c];
+        mu[j] = mean[c];
+        is[j] = invstd[c];
+        ka[j] = training ? (float)(s / M) : 0.f;
+        kb[j] = training ? (float)(sx / M) : 0.f;
+    }
+    const int items = H * Wq;
+    const long long plane = (long long)H * Wq;
+    for (int n = p; n < N; n += P) {
+        for (int it = threadIdx.x; it < items; it += BN_THREADS) {
+            const int h = it / Wq, wq = it - h * Wq;
+            uint4 dz[4];
+            bnps_load(dout, (long long)n * G + g, h, wq, H, Wq, dz);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long off = ((long long)n * C + 4 * g + j) * plane + it;
+                float f[8], gd[8], o[8];
+                unpack16<T>(x[off], f);
+                unpack16<T>(dz[j], gd);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = k1[j] * (gd[e] - ka[j] - (f[e] - mu[j]) * is[j] * kb[j]);
+                dx[off] = pack16<T>(o);
+            }
+        }
+    }
+}
+
 static int bn_parts(int64_t N, int64_t C) {
     // enough blocks to fill the chip (256 CUs x ~8 blocks), at most one image per part
     int64_t want = cdiv(2048, C > 0 ? C : 1);
@@ -918,6 +1036,57 @@ int bn_bwd_reduce_only(const void* dy, const void* x, const float* scale, const 
     return check_launch(name);
 }
 }  // namespace ofasr
+
+OFASR_EXPORT size_t ofasr_bn_bwd_ps2_workspace(int64_t N, int64_t C) {
+    if (N <= 0 || C < 4) return 0;
+    return (size_t)bn_parts(N, C / 4) * C * 2 * sizeof(double);
+}
+
+// BatchNorm backward of a layer whose output went through PixelShuffle(2): dout is the gradient in the SHUFFLED layout
+// [N, C/4, 2H, 2W]; dx, dgamma, dbeta as ofasr_bn_act_bwd with act = 0 and no residual.  f16 / bf16, W % 8 == 0,
+// C % 4 == 0, 16-byte aligned tensors; workspace: ofasr_bn_bwd_ps2_workspace(N, C) bytes.
+OFASR_EXPORT int ofasr_bn_bwd_ps2(const void* dout, const void* x, void* dx, const float* scale, const float* mean,
+                                  const float* invstd, float* dgamma, float* dbeta, int64_t N, int64_t C, int64_t H, int64_t W,
+                                  int training, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    const char* name = "ofasr_bn_bwd_ps2";
+    int rc = check_bn(name, N, C, H * W, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(dout && x && dx && scale && mean && invstd, OFASR_ERR_INVALID_ARG, "%s: null pointer", name);
+    OFASR_REQUIRE(dtype == OFASR_F16 || dtype == OFASR_BF16, OFASR_ERR_UNSUPPORTED, "%s: 16-bit tensors only", name);
+    OFASR_REQUIRE(C % 4 == 0 && W % 8 == 0 && H <= (1 << 20) && W <= (1 << 20), OFASR_ERR_UNSUPPORTED,
+                  "%s: needs C %% 4 == 0 and W %% 8 == 0", name);
+    OFASR_REQUIRE(((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0,
+                  OFASR_ERR_UNSUPPORTED, "%s: tensors must be 16-byte aligned", name);
+    const int P = bn_parts(N, C / 4);
+    const size_t need = (size_t)P * C * 2 * sizeof(double);
+    OFASR_REQUIRE(workspace && workspace_bytes >= need, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", name,
+                  workspace_bytes, need);
+    double* partial = (double*)workspace;
+    const int Wq = (int)(W / 8);
+    const double M = (double)N * (double)H * (double)W;
+    dim3 grid((unsigned)(C / 4), (unsigned)P);
+    hipStream_t st = as_stream(stream);
+    const double tensor_bytes = 2.0 * (double)N * (double)C * (double)H * (double)W;
+    prof_note(2.0 * tensor_bytes, 0.0);
+    if (dtype == OFASR_BF16)
+        OFASR_LAUNCH((bn_bwd_reduce_ps_kernel<bf16_t>), grid, dim3(BN_THREADS), 0, st, (const uint4*)dout, (const uint4*)x, mean,
+                     invstd, partial, (int)N, (int)C, (int)H, Wq, P);
+    else
+        OFASR_LAUNCH((bn_bwd_reduce_ps_kernel<f16_t>), grid, dim3(BN_THREADS), 0, st, (const uint4*)dout, (const uint4*)x, mean,
+                     invstd, partial, (int)N, (int)C, (int)H, Wq, P);
+    rc = check_launch(name);
+    if (rc) return rc;
+    prof_note(3.0 * tensor_bytes, 0.0);
+    if (dtype == OFASR_BF16)
+        OFASR_LAUNCH((bn_bwd_apply_ps_kernel<bf16_t>), grid, dim3(BN_THREADS), 0, st, (const uint4*)dout, (const uint4*)x,
+                     (uint4*)dx, scale, mean, invstd, (const double*)partial, P, M, training, dgamma, dbeta, (int)N, (int)C,
+                     (int)H, Wq, P);
+    else
+        OFASR_LAUNCH((bn_bwd_apply_ps_kernel<f16_t>), grid, dim3(BN_THREADS), 0, st, (const uint4*)dout, (const uint4*)x,
+                     (uint4*)dx, scale, mean, invstd, (const double*)partial, P, M, training, dgamma, dbeta, (int)N, (int)C,
+                     (int)H, Wq, P);
+    return check_launch(name);
+}
 
 OFASR_EXPORT size_t ofasr_bn_act_bwd_workspace(int64_t N, int64_t C) {
     if (N <= 0 || C <= 0) return 0;

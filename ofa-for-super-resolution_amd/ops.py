@@ -451,6 +451,20 @@ class BNActCPFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, stats = ctx.saved_tensors
+        if ctx.shuffled and PS_BWD_FUSED:
+            # both BatchNorm-backward passes read the gradient through the inverse shuffle (no un-shuffle pass)
+            N, C, H, W = x.shape
+            L = _C.lib()
+            dy = dy.contiguous()
+            dx = torch.empty_like(x)
+            wshape = ctx.meta[3]
+            full = int(wshape[0]) == C
+            gb = (torch.empty if full else torch.zeros)((2,) + tuple(wshape), dtype=torch.float32, device=x.device)
+            wst, wsp, wsn = _ws(L.ofasr_bn_bwd_ps2_workspace(N, C), x.device)
+            with _timed("bn_bwd_ps2", 5 * x.numel() * x.element_size()):
+                _C.check(L.ofasr_bn_bwd_ps2(_p(dy), _p(x), _p(dx), _p(stats[2]), _p(stats[0]), _p(stats[1]), _p(gb[0]),
+                                            _p(gb[1]), N, C, H, W, 1, _dt(x), wsp, wsn, _stream()), "bn_bwd_ps2")
+            return dx, None, gb[0], gb[1], None, None, None, None, None
         if ctx.shuffled:
             dy = _shuffle_raw(dy.contiguous(), 2, True)
         dx, dgamma, dbeta, _ = _bn_act_backward(x, stats, None, ctx.meta, dy)
@@ -987,6 +1001,7 @@ def _conv2d_backward(ctx, dy):
 
 ACT_PIXEL_SHUFFLE2 = 2   # ofasr_conv2d_infer_run's act codes: 0 none, 1 ReLU6 (= ACT_RELU6), 2 PixelShuffle(2) store
 CONV_BN_EPILOGUE = os.environ.get("OFASR_CONV_BN_EPILOGUE", "1") != "0"
+PS_BWD_FUSED = os.environ.get("OFASR_PS_BWD_FUSED", "1") != "0"   # BN backward reads dout through the inverse PixelShuffle
 
 
 def conv_bn_act_train(x, conv, bn, act):

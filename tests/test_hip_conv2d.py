@@ -320,7 +320,11 @@ def test_conv_layer_training_epilogue_statistics_vs_oracle(ora, case, dtype):
 
     # backward against the un-fused HIP path on the same layer (itself oracle-tested): same gradients
     dy = r16(det_uniform(tuple(y.shape), "cvt/dy%s" % (case,)))
+    C.reset_launch_counts()
     y.backward(torch.from_numpy(dy).to(dtype).to(DEV))
+    if act == "pixelshuffle":   # the BN backward reads the gradient through the inverse shuffle: no un-shuffle pass
+        assert C.launch_count("ps_r2_kernel") == 0 and C.launch_count("ps_generic") == 0, C.launch_table()
+        assert C.launch_count("bn_bwd_reduce_ps_kernel") == 1 and C.launch_count("bn_bwd_apply_ps_kernel") == 1
     got = [xt.grad.float().cpu().numpy(), layer.conv.weight.grad.cpu().numpy(), layer.bn.weight.grad.cpu().numpy(),
            layer.bn.bias.grad.cpu().numpy()]
     for p in (layer.conv.weight, layer.bn.weight, layer.bn.bias):
