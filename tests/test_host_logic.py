@@ -174,3 +174,48 @@ def test_count_net_flops_matches_survey(net):
         type(net).COMPAT_REFERENCE_INDEXING = True
     # 28.0 GFLOP forward per image for k7/e6/d4 at 64x64 -> 256x256 (= 14.0 GMAC)
     assert abs(2 * macs / 1e9 - 28.0) < 0.3, macs
+
+
+def test_infer_operand_cache_identity_versions_and_epoch():
+    """ops._infer_operands (host logic, CPU tensors): operands are reused only for the SAME tensor objects at the same
+    address and version; an in-place update, a new tensor object (even at a recycled address) or clear_infer_cache()
+    prepares again; the epoch counter GraphedEval keys on moves with every clear."""
+    import gc
+
+    import torch
+
+    ops = amd("ops")
+    ops.clear_infer_cache()
+    calls = []
+
+    def prepare(ptr, nbytes):
+        calls.append(int(nbytes.value))
+
+    w = torch.zeros(8)
+    b = torch.ones(8)
+    buf0 = ops._infer_operands(("k", 1), (w, b, None), 64, "cpu", prepare)
+    buf1 = ops._infer_operands(("k", 1), (w, b, None), 64, "cpu", prepare)
+    assert buf0 is buf1 and len(calls) == 1
+    assert ops._infer_operands(("k", 2), (w, b, None), 64, "cpu", prepare) is not buf0 and len(calls) == 2   # other kind
+    w.add_(1.0)                                                  # tracked in-place write: version bump
+    buf2 = ops._infer_operands(("k", 1), (w, b, None), 64, "cpu", prepare)
+    assert buf2 is not buf0 and len(calls) == 3
+    # a different tensor object never matches an entry made for another one, whatever its address / version
+    w2 = w.clone()
+    assert ops._infer_operands(("k", 1), (w2, b, None), 64, "cpu", prepare) is not buf2 and len(calls) == 4
+    ptr, ver = w2.data_ptr(), w2._version
+    del w2
+    gc.collect()
+    for _ in range(64):                                          # try to get a new tensor at the recycled address
+        w3 = torch.empty(8)
+        if w3.data_ptr() == ptr and w3._version == ver:
+            n = len(calls)
+            ops._infer_operands(("k", 1), (w3, b, None), 64, "cpu", prepare)
+            assert len(calls) == n + 1, "an entry outlived the tensor it was built from"
+            break
+    e0 = ops.infer_epoch()
+    ops.clear_infer_cache()
+    assert ops.infer_epoch() == e0 + 1 and not ops.infer_operand_buffers()
+    ops._infer_operands(("k", 1), (w, b, None), 64, "cpu", prepare)
+    assert len(ops.infer_operand_buffers()) == 1
+    ops.clear_infer_cache()
