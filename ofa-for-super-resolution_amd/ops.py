@@ -885,16 +885,31 @@ class Conv2dF32Fn(Function):
                 dx, need_dx = vdx, False
             if need_dw and not wgrad_own:
                 dw, need_dw = vdw, False
+        defer = False
         if need_dw:
             dw = torch.empty_like(weight)
             wst2, wsp2, wsn2 = _ws(L.ofasr_conv2d_f32_wgrad_workspace(N, Cin, Cout, H, W, K), x.device)
-            _C.check(L.ofasr_conv2d_f32_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Cout, H, W, K, wsp2, wsn2, _stream()),
-                     "conv2d_f32_wgrad")
+            # as Conv2dFn: the weight gradient of a large-plane conv goes to the library's side stream and is joined with the
+            # composite blocks' at the end of the backward pass
+            side = None
+            if CONV_DEFER_WGRAD and H * W >= CONV_DEFER_MIN_HW and _lib_side_stream(x.device) is not None:
+                defer = _defer_this_backward((weight,))
+                if defer:
+                    side = _lib_side_stream(x.device)
+                    side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(x.device)):
+                _C.check(L.ofasr_conv2d_f32_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Cout, H, W, K, wsp2, wsn2, _stream()),
+                         "conv2d_f32_wgrad")
         if need_dx:
             dx = torch.empty_like(x)
             wst, wsp, wsn = _ws(L.ofasr_conv2d_f32_workspace(Cin, Cout, K, 1), x.device)
             _C.check(L.ofasr_conv2d_f32_dgrad(_p(dy), _p(weight), _p(dx), N, Cin, Cout, H, W, K, wsp, wsn, _stream()),
                      "conv2d_f32_dgrad")
+        if defer:
+            _Deferred.keep.append((x, dy, dw, wst2, weight))
+            _Deferred.grads.append((weight, dw))
+            _Deferred.ext_used.add(torch.device(x.device).index or 0)
+            return dx, None
         return dx, dw
 
 
