@@ -39,7 +39,8 @@
 extern "C" {
 #endif
 
-#define OFASR_VERSION 100 /* 0.1.0 */
+/* major*100 + minor: the minor number moves whenever the exported set below changes (tests/test_abi.py reads it here) */
+#define OFASR_VERSION 300 /* round 3 */
 
 typedef enum {
     OFASR_OK = 0,

@@ -64,17 +64,27 @@ def set_running_statistics(model, data_loader, input_key="image", device=None, d
             m.forward = hook(m, name)
 
     from .. import ops
-    flag, fused = DynamicBatchNorm2d.SET_RUNNING_STATISTICS, ops.FUSED_BN
+    from ..utils import device_batch
+    flag, fused, fused_infer = DynamicBatchNorm2d.SET_RUNNING_STATISTICS, ops.FUSED_BN, ops.FUSED_INFER
     DynamicBatchNorm2d.SET_RUNNING_STATISTICS = True
-    ops.FUSED_BN = False   # every BatchNorm2d must go through its (hooked) module forward, static ConvLayers included
+    # every BatchNorm2d must go through its (hooked) module forward, static ConvLayers included: neither the fused
+    # BatchNorm passes nor the one-kernel inference layers / blocks (which fold the OLD running statistics) may run
+    ops.FUSED_BN = False
+    ops.FUSED_INFER = False
     try:
         with torch.no_grad():
             for batch in data_loader:
-                x = batch[input_key] if isinstance(batch, dict) else batch[0]
+                if isinstance(batch, dict):
+                    if input_key not in batch:      # lr_on_device providers hand over {'image_u8'} only
+                        batch = device_batch(batch, device)
+                    x = batch[input_key]
+                else:
+                    x = batch[0]
                 forward_model(x.to(device))
     finally:
         DynamicBatchNorm2d.SET_RUNNING_STATISTICS = flag
         ops.FUSED_BN = fused
+        ops.FUSED_INFER = fused_infer
 
     for name, m in model.named_modules():
         rec = stats.get(name)
@@ -83,3 +93,6 @@ def set_running_statistics(model, data_loader, input_key="image", device=None, d
         c = rec["mean_sum"].numel()
         m.running_mean.data[:c].copy_(rec["mean_sum"] / rec["n"])
         m.running_var.data[:c].copy_(rec["var_sum"] / rec["n"])
+    # the .data writes above are invisible to the version counters the inference operand cache (BN-folded weight
+    # images) and GraphedEval key on: drop both, or the next eval forward replays the OLD running statistics
+    ops.clear_infer_cache()

@@ -11,7 +11,8 @@ A captured graph holds raw device pointers -- the weights, the prepared inferenc
 its private activation pool -- so a graph is only replayed while the network is in the state it was captured in:
 the key is (input shape / dtype, autocast dtype, the active sub-network's description, and (address, version) of
 every parameter and buffer).  Any optimizer step, load_state_dict, re-organisation or set_active_subnet therefore
-leads to a fresh capture, and stale graphs are dropped (least recently used first).
+leads to a fresh capture; graphs of an earlier operand-cache epoch (ops.clear_infer_cache) are dropped at once,
+the rest least recently used first.
 
 Mirror of nothing in the reference (its eval loop, eval_ofa_net_sr.py:187-220, calls the module eagerly); used by
 SRRunManager.validate_batched, eval_ofa_net_sr.py and bench.py --config c5.
@@ -30,6 +31,7 @@ class GraphedEval(object):
         self.max_graphs = max_graphs
         self.copy_output = copy_output
         self._graphs = collections.OrderedDict()
+        self._epoch = ops.infer_epoch()
         self.captures = 0
         self.replays = 0
 
@@ -41,8 +43,11 @@ class GraphedEval(object):
             arch = net.module_str
         except (AttributeError, NotImplementedError):
             arch = None
+        # BN eps is folded into the prepared operands but is a plain float (set_bn_param rewrites it without touching
+        # any tensor); the two switches select which kernels a forward launches
+        eps = tuple(m.eps for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm))
         # the operand cache's epoch: bumped by everything that rewrites weights behind the version counters
-        return arch, hash(tensors), ops.infer_epoch()
+        return arch, hash(tensors), hash(eps), ops.FUSED_INFER, ops.INFER_CACHE, ops.infer_epoch()
 
     def _forward(self, x):
         if self.autocast_dtype is None:
@@ -73,6 +78,11 @@ class GraphedEval(object):
             raise RuntimeError("GraphedEval needs the network (and its BatchNorm layers) in eval mode")
         if not x.is_cuda:
             raise RuntimeError("GraphedEval needs a GPU tensor")
+        if self._epoch != ops.infer_epoch():
+            # weights were rewritten behind the version counters (or the net went through .train()): no graph captured
+            # before can match again -- free their activation pools and operand buffers now rather than by LRU
+            self._graphs.clear()
+            self._epoch = ops.infer_epoch()
         key = (tuple(x.shape), x.dtype, str(x.device), self.autocast_dtype) + self._state()
         entry = self._graphs.get(key)
         if entry is None:

@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libofasr_hip.so does not export %s" % name
     assert set(declared) == set(C.SIGNATURES), "ctypes table and header drifted apart"
-    assert L.ofasr_version() == 100
+    hdr = open(os.path.join(ROOT, "include", "ofasr.h")).read()
+    assert L.ofasr_version() == int(re.search(r"#define OFASR_VERSION (\d+)", hdr).group(1)) >= 300
     assert L.ofasr_status_string(-2) == b"unsupported shape or dtype"
 
 

@@ -282,3 +282,46 @@ def test_bn_recalibration_golden(mods, golden):
             assert_close(H(v), ref, 2e-4, 2e-5 * max(1.0, float(np.abs(ref).max())), k)
             changed += int(not torch.equal(v, before[k]))
     assert changed > 40   # the active BNs were re-estimated, inactive ones (skipped depth) keep their values
+
+
+def test_recalibration_invalidates_inference_operands(mods, golden):
+    """set_running_statistics writes the new statistics through `.data` (no version bump), so the
+    BN-folded operand cache and GraphedEval's captured graphs must be dropped by it.  bf16 eval forward ->
+    re-calibration -> eval forward must equal the same sequence with the operand cache switched off, and GraphedEval
+    must capture again."""
+    g = golden("calibration.npz")
+    eutils, ops = amd("elastic_nn.utils"), amd("ops")
+    graphed = amd("graphed")
+
+    def run(cache):
+        was = ops.INFER_CACHE
+        ops.INFER_CACHE = cache
+        ops.clear_infer_cache()
+        try:
+            net = mods["nets"].OFAMobileNetS4(ks_list=[3, 5, 7], expand_ratio_list=[3, 4, 6], depth_list=[2, 3, 4],
+                                              pixelshuffle_depth_list=[1, 2])
+            _load(net, "s4")
+            net = net.to(DEV).eval()
+            net.set_active_subnet(ks=5, e=4, d=3, pixel_d=2)
+            x = G(g["b0"])[:2]
+            ge = graphed.GraphedEval(net, autocast_dtype=torch.bfloat16)
+            with torch.no_grad():
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y0 = net(x).float().clone()
+                z0 = ge(x).float().clone()
+                c0 = ge.captures
+                eutils.set_running_statistics(net, [{"image": G(g["b0"])}, {"image": G(g["b1"])}])
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y1 = net(x).float().clone()
+                z1 = ge(x).float().clone()
+            return y0, y1, z0, z1, ge.captures - c0
+        finally:
+            ops.INFER_CACHE = was
+            ops.clear_infer_cache()
+
+    y0, y1, z0, z1, recaptured = run(True)
+    u0, u1, _, _, _ = run(False)
+    assert torch.equal(y0, u0) and torch.equal(z0, y0)
+    assert not torch.equal(y0, y1), "re-calibration must change the eval output"
+    assert torch.equal(y1, u1), "cached inference operands survived set_running_statistics"
+    assert recaptured == 1 and torch.equal(z1, y1), "GraphedEval replayed a graph of the old running statistics"
