@@ -14,11 +14,16 @@
 
 Prints ONE JSON line on rank 0.  Besides the contract fields it carries
   roofline      the kernel of the HIP library with the largest total time over the profiled steps (ALL library kernels
-                compete, on whichever stream they ran), timed live with HIP events recorded on the stream each kernel is
-                launched on (ofasr_profile_enable, include/ofasr.h) on the SAME composite path the timed region runs;
+                compete, on whichever stream they ran), timed live with HIP events attached to each kernel's own dispatch
+                (hipExtLaunchKernel start / stop events, ofasr_profile_enable in include/ofasr.h: the kernel's begin -> end
+                time as rocprofv3's kernel trace reports it, no barrier packets added, streams overlap as in the timed
+                region) on the SAME composite path the timed region runs; `trace_avg_us` beside it is the average of the
+                same symbol in the committed rocprofv3 trace of the same command (profiles/trace_summary.json, static);
   kernels       the per-kernel table of those profiled steps (symbol = the name rocprofv3 prints);
-  pointwise     the 1x1 path's MFMA TFLOP/s against the bf16 MFMA peak (north_star quotes its target against it);
-  fp32          (c3, dtype != f32) the same training step with fp32 activations -- the reference's arithmetic;
+  pointwise     the 1x1 path's MFMA TFLOP/s against the MFMA peak of the dtype (north_star quotes its target against it);
+  fp32          (c3, dtype != f32) the same training step with fp32 activations -- the reference's arithmetic -- as a
+                complete leg of its own: value, ms_per_step, roofline, pointwise, kernels (`--dtype f32` makes it the
+                headline of the line instead);
   cpu_baseline  the CPU oracle port of the same training step timed on the host cores in this run.
 """
 import argparse
@@ -222,13 +227,25 @@ def roofline_from(summ, nprof, dtype):
     cands = {k: v for k, v in summ.items() if v["launches"] > 0 and v["bytes"] > 0}
     if not cands:
         return None, table, None
-    name, top = max(cands.items(), key=lambda kv: kv[1]["total_us"])
+    # the dominant kernel: the one the committed rocprofv3 trace of this command puts on top (so that the line and
+    # profiles/ talk about the same kernel); without a trace for this dtype, the top of the live event table
+    name, chosen_by = None, "live event table (largest total time over the profiled steps)"
+    tr = trace_table(dtype)
+    if tr:
+        for k, _ in sorted(tr.items(), key=lambda kv: -kv[1].get("ms_per_step", 0.0)):
+            if k in cands:
+                name, chosen_by = k, "top library kernel of profiles/trace_summary.json (rocprofv3 --kernel-trace, static)"
+                break
+    if name is None:
+        name = max(cands.items(), key=lambda kv: kv[1]["total_us"])[0]
+    top = cands[name]
     secs = top["total_us"] * 1e-6
     peak_tf = MFMA_PEAK_TF[dtype]
     # which roof bounds the kernel: its algorithmic intensity against the ridge (peak flops / peak bytes); the one-kernel
     # MB block (9.3 GFLOP over 25 MB at N=16: 370 flop/B, ridge 312) and the static convs sit on the matrix side
     mfma_bound = top["flops"] > 0 and top["flops"] / top["bytes"] > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
     traffic, source = pmc_traffic(name)
+    trace_us, trace_src = trace_avg(name, dtype)
     if mfma_bound:
         ach = top["flops"] / secs / 1e12
         roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 1), "peak": peak_tf, "unit": "TFLOP/s",
@@ -243,7 +260,13 @@ def roofline_from(summ, nprof, dtype):
                  "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
                  "hbm_gbps": round(top["bytes"] / secs / 1e9, 1),
                  "mfma_tflops": round(top["flops"] / secs / 1e12, 2) if top["flops"] > 0 else None,
-                 "timing": "HIP events on the launch stream, composite path, %d profiled steps" % nprof,
+                 "chosen_by": chosen_by,
+                 "trace_avg_us": trace_us, "trace_source": trace_src,
+                 "frac_trace": (round((top["flops"] if mfma_bound else top["bytes"]) / top["launches"] / (trace_us * 1e-6)
+                                      / ((peak_tf * 1e12) if mfma_bound else (HBM_PEAK_GBS * 1e9)), 4)
+                                if trace_us else None),
+                 "timing": "start/stop events attached to each kernel dispatch (hipExtLaunchKernel), composite path, "
+                           "%d profiled steps, both streams live" % nprof,
                  "hip_library_ms_per_step": round(sum(v["total_us"] for v in summ.values()) * 1e-3 / nprof, 3)})
     # the 1x1 path (north_star: >= 70 % of the fp16/bf16 MFMA roofline is quoted against this)
     pw = [v for k, v in summ.items() if k.startswith("pw_") and v["flops"] > 0]
@@ -257,6 +280,31 @@ def roofline_from(summ, nprof, dtype):
                      "algorithmic_intensity_flop_per_byte": round(fl / by, 1),
                      "ms_per_step": round(t * 1e3 / nprof, 3)}
     return roof, table, pointwise
+
+
+def trace_table(dtype):
+    try:
+        with open(os.path.join(ROOT, "profiles", "trace_summary.json")) as f:
+            return json.load(f).get(dtype, {}).get("kernels", {})
+    except Exception:
+        return {}
+
+
+def trace_avg(kernel, dtype):
+    """average duration (us) of `kernel` in the committed rocprofv3 --kernel-trace of the same command
+    (profiles/trace_summary.json, written by tools/prof_round.sh through profiles/trace_steps.py --json) -- a static
+    cross-check of the live event timing, NOT measured by this run."""
+    path = os.path.join(ROOT, "profiles", "trace_summary.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except Exception:
+        return None, None
+    sect = table.get(dtype, {})
+    hit = sect.get("kernels", {}).get(kernel)
+    if hit is None:
+        return None, None
+    return hit.get("avg_us"), "profiles/trace_summary.json (%s)" % sect.get("source", "rocprofv3 --kernel-trace")
 
 
 def pmc_traffic(kernel):
@@ -348,44 +396,46 @@ def main():
         torch.cuda.synchronize()
 
     S = args.lr_size or (48 if args.config == "c2" else 64)
-    if args.config == "c5":
-        wl = EvalWorkload(M, dev, args.dtype, graphs=not args.no_graphs)
-        per_step = wl.n_images
-    else:
-        wl = TrainWorkload(M, args.config, dev, args.batch, S, args.dtype, world, rank, args.h2d)
-        per_step = args.batch
-    dt, last = timed(wl.step, args.warmup, args.steps, fence)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = 1e3 * dt / args.steps
-    value = world * per_step * args.steps / dt
-    final_loss = float(last.detach()) if args.config != "c5" else None
 
-    roofline = kernel_table = pointwise = None
-    if not args.no_roofline:   # every rank runs the profiled steps (they contain the gradient all-reduce); rank 0 reports
-        nprof = min(args.steps, 6)
-        # (a replayed graph runs no host code, so the event brackets need the eager launches of the same kernels)
-        prof_step = (lambda i: wl.step(i, eager=True)) if args.config == "c5" else wl.step
-        summ = profile_steps(M, prof_step, args.warmup + args.steps, nprof)
-        roofline, kernel_table, pointwise = roofline_from(summ, nprof, args.dtype)
+    def leg(dtype, warmup, steps, h2d):
+        """one timed leg (warm-up, EXACTLY `steps` timed steps between two fences, max over ranks) + its profiled steps"""
+        if args.config == "c5":
+            wl = EvalWorkload(M, dev, dtype, graphs=not args.no_graphs)
+            per_step = wl.n_images
+        else:
+            wl = TrainWorkload(M, args.config, dev, args.batch, S, dtype, world, rank, h2d)
+            per_step = args.batch
+        dt, last = timed(wl.step, warmup, steps, fence)
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        out = {"value": round(world * per_step * steps / dt, 2), "unit": "images/s",
+               "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup, "dtype": dtype,
+               "final_loss": float(last.detach()) if args.config != "c5" else None}
+        if not args.no_roofline:   # every rank runs the profiled steps (they contain the gradient all-reduce); rank 0 reports
+            nprof = min(steps, 6)
+            # (a replayed graph runs no host code, so the per-dispatch events need the eager launches of the same kernels)
+            prof_step = (lambda i: wl.step(i, eager=True)) if args.config == "c5" else wl.step
+            summ = profile_steps(M, prof_step, warmup + steps, nprof)
+            out["roofline"], out["kernels"], out["pointwise"] = roofline_from(summ, nprof, dtype)
+        else:
+            out["roofline"] = out["kernels"] = out["pointwise"] = None
+        extra = {"n_params": wl.n_params, "buckets": len(wl.buckets) if args.config == "c5" else None,
+                 "graphed": args.config == "c5" and wl.graphed is not None, "per_step": per_step}
+        del wl
+        torch.cuda.empty_cache()
+        return out, extra
+
+    main_leg, info = leg(args.dtype, args.warmup, args.steps, args.h2d)
+    value, ms_per_step, final_loss = main_leg["value"], main_leg["ms_per_step"], main_leg["final_loss"]
+    roofline, kernel_table, pointwise = main_leg["roofline"], main_leg["kernels"], main_leg["pointwise"]
+    per_step = info["per_step"]
 
     fp32 = None
     if args.config == "c3" and args.dtype != "f32" and not args.no_fp32:
-        # the reference computes in fp32: the same step with fp32 activations, a short leg of its own
-        del wl
-        torch.cuda.empty_cache()
-        wl32 = TrainWorkload(M, "c3", dev, args.batch, S, "f32", world, rank, False)
-        dt32, l32 = timed(wl32.step, 3, args.fp32_steps, fence)
-        if world > 1:
-            t = torch.tensor([dt32], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt32 = float(t.item())
-        fp32 = {"value": round(world * args.batch * args.fp32_steps / dt32, 2), "unit": "images/s",
-                "ms_per_step": round(1e3 * dt32 / args.fp32_steps, 3), "steps": args.fp32_steps, "warmup": 3,
-                "dtype": "f32", "final_loss": float(l32.detach())}
-        del wl32
+        # the reference computes in fp32 (SURVEY.md 8): the same step with fp32 activations, a complete leg of its own
+        fp32, _ = leg("f32", 3, args.fp32_steps, False)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "c3":
@@ -404,8 +454,8 @@ def main():
             metric = "sr_inference_images_per_sec_4x_set14_sizes"
             workload = ("sampled sub-network (ks=7, e=6, d=2, pixel_d=2) 4x inference over the 14 Set14 image sizes "
                         "(LR 62x90 .. 192x128), eval-mode BN, equal sizes batched: %d forward calls per pass "
-                        "(BASELINE config 5)" % len(wl.buckets))
-        cfg = {"workload": workload, "params": wl.n_params if args.config == "c5" else None,
+                        "(BASELINE config 5)" % info["buckets"])
+        cfg = {"workload": workload, "params": info["n_params"] if args.config == "c5" else None,
                "kernel_transform_mode": 1, "compat_reference_indexing": True, "parallelism": "dp%d" % world}
         if args.config != "c5":
             cfg.update({"per_gpu_batch": args.batch, "global_batch": args.batch * world,
@@ -414,10 +464,10 @@ def main():
         else:
             cfg["images_per_pass"] = per_step
             cfg["launch"] = ("one hipGraph replay per size bucket (graphed.GraphedEval); kernel table from eager launches"
-                             if wl.graphed is not None else "eager")
+                             if info["graphed"] else "eager")
         line = {
-            "metric": metric, "value": round(value, 2), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "metric": metric, "value": value, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic", "config": cfg, "roofline": roofline, "pointwise": pointwise, "fp32": fp32,
             "cpu_baseline": cpu_baseline, "kernels": kernel_table,

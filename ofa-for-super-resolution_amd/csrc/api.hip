@@ -23,8 +23,8 @@ namespace {
 std::mutex g_prof_mu;
 LaunchSite* g_sites = nullptr;
 struct ProfRec {
+    ProfEvents ev;   // first member: prof_begin hands out &ev
     LaunchSite* site;
-    hipEvent_t t0, t1;
     double bytes, flops;
 };
 std::vector<ProfRec*> g_recs;       // launches bracketed since the last ofasr_profile_enable(1)
@@ -83,26 +83,17 @@ void prof_note(double bytes, double flops) {
     t_note_flops = flops;
 }
 
-void* prof_begin(LaunchSite* s, hipStream_t st) {
+ProfEvents* prof_begin(LaunchSite* s) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     hipEvent_t a = take_event(), b = take_event();
-    if (!a || !b) return nullptr;
-    ProfRec* r = new ProfRec{s, a, b, t_note_bytes, t_note_flops};
-    t_note_bytes = t_note_flops = 0.0;
-    if (hipEventRecord(a, st) != hipSuccess) {
-        (void)hipGetLastError();
-        g_ev_pool.push_back(a);
-        g_ev_pool.push_back(b);
-        delete r;
+    if (!a || !b) {
+        if (a) g_ev_pool.push_back(a);
         return nullptr;
     }
+    ProfRec* r = new ProfRec{{a, b}, s, t_note_bytes, t_note_flops};
+    t_note_bytes = t_note_flops = 0.0;
     g_recs.push_back(r);
-    return r;
-}
-
-void prof_end(void* rec, hipStream_t st) {
-    ProfRec* r = (ProfRec*)rec;
-    if (hipEventRecord(r->t1, st) != hipSuccess) (void)hipGetLastError();
+    return &r->ev;
 }
 }  // namespace ofasr
 
@@ -138,6 +129,18 @@ OFASR_EXPORT const char* ofasr_debug_launch_table(void) {
 OFASR_EXPORT int ofasr_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     const int was = g_profile_on;
+    if (on) {
+        // events for ~5 steps of the training path up front: creating them launch by launch slows the host enough to
+        // change how the two streams overlap, i.e. the regime that is being measured
+        while (g_ev_pool.size() < 6144) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
+            g_ev_pool.push_back(e);
+        }
+    }
     g_profile_on = on ? 1 : 0;
     return was;
 }
@@ -156,7 +159,7 @@ OFASR_EXPORT const char* ofasr_profile_read(void) {
     std::vector<std::pair<LaunchSite*, Agg>> agg;
     for (ProfRec* r : recs) {
         float ms = 0.f;
-        const bool ok = hipEventSynchronize(r->t1) == hipSuccess && hipEventElapsedTime(&ms, r->t0, r->t1) == hipSuccess;
+        const bool ok = hipEventSynchronize(r->ev.t1) == hipSuccess && hipEventElapsedTime(&ms, r->ev.t0, r->ev.t1) == hipSuccess;
         if (!ok) (void)hipGetLastError();
         Agg* a = nullptr;
         for (auto& kv : agg)
@@ -174,8 +177,8 @@ OFASR_EXPORT const char* ofasr_profile_read(void) {
     }
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (ProfRec* r : recs) {
-        g_ev_pool.push_back(r->t0);
-        g_ev_pool.push_back(r->t1);
+        g_ev_pool.push_back(r->ev.t0);
+        g_ev_pool.push_back(r->ev.t1);
         delete r;
     }
     g_report.clear();

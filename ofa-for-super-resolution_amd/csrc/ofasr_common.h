@@ -1,6 +1,9 @@
 // ofasr_common.h -- shared device/host helpers for the gfx950 kernels.  HIP only, CDNA4 only.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <tuple>
+#include <utility>
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/ofasr.h"
@@ -27,10 +30,14 @@ inline int check_launch(const char* what) {
 // LaunchSite (its name is the fully resolved, demangled kernel symbol the runtime reports for the host stub -- the
 // name rocprofv3 prints, minus the parameter list) with a launch counter --
 // tests assert the routing of a call through it (ofasr_debug_launch_count) -- and, while profiling is switched on
-// (ofasr_profile_enable), the launch is bracketed by two events recorded on the stream it is launched on, so
-// bench.py's per-kernel table and `roofline` describe the kernels the timed step really ran, whichever stream
-// (caller's or the library's side stream) they ran on.  prof_note() attaches algorithmic bytes / flops to the next
-// launch of this host thread.  With profiling off the cost per launch is one relaxed increment.
+// (ofasr_profile_enable), the launch carries its own start / stop events (hipExtLaunchKernelGGL: the two events are
+// attached to the kernel's dispatch packet, so their difference is the kernel's begin -> end time as the GPU's
+// completion signal records it -- the duration rocprofv3's kernel trace prints -- with no extra barrier packet on the
+// stream: launch gaps are not counted and kernels of the two streams overlap exactly as in the un-profiled step).
+// bench.py's per-kernel table and `roofline` therefore describe the kernels the timed step really ran, in the regime
+// it ran them, whichever stream (caller's or the library's side stream) they ran on.  prof_note() attaches
+// algorithmic bytes / flops to the next launch of this host thread.  With profiling off the cost per launch is one
+// relaxed increment.
 struct LaunchSite {
     const char* name;
     unsigned long long count;
@@ -43,16 +50,47 @@ template <auto F> inline LaunchSite* launch_site(const char* spelled) {
 }
 extern int g_profile_on;
 void prof_note(double bytes, double flops);
-void* prof_begin(LaunchSite* s, hipStream_t st);
-void prof_end(void* rec, hipStream_t st);
+struct ProfEvents {
+    hipEvent_t t0, t1;
+};
+ProfEvents* prof_begin(LaunchSite* s);
+// kernel<<<grid, block, shmem, stream>>>(args...) with the two events attached to the dispatch itself; the actual
+// arguments are converted to the kernel's formal parameter types first, as the triple-chevron launch does
+template <typename... F, size_t... I>
+inline void ext_launch_tuple(void (*kernel)(F...), dim3 grid, dim3 block, unsigned shmem, hipStream_t st, ProfEvents* ev,
+                             std::tuple<F...>& formals, std::index_sequence<I...>) {
+    void* ptrs[sizeof...(F) ? sizeof...(F) : 1] = {(void*)&std::get<I>(formals)...};
+    (void)hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, shmem, st, ev->t0, ev->t1, 0);
+}
+template <size_t I, typename Fi, typename Tup> inline Fi ext_arg(Tup& actuals) {
+    // trailing parameters a call leaves to their defaults: every default in csrc/ is the value-initialised object
+    // (nullptr, InputXf{}, BwdXf{}, BnFold{}, StatOut{nullptr, 0})
+    if constexpr (I < std::tuple_size<Tup>::value) return static_cast<Fi>(std::get<I>(actuals));
+    else return Fi{};
+}
+template <typename... F, size_t... I, typename Tup>
+inline void ext_launch_conv(void (*kernel)(F...), dim3 grid, dim3 block, unsigned shmem, hipStream_t st, ProfEvents* ev,
+                            Tup& actuals, std::index_sequence<I...> seq) {
+    std::tuple<F...> formals{ext_arg<I, F>(actuals)...};
+    ext_launch_tuple(kernel, grid, block, shmem, st, ev, formals, seq);
+}
+template <typename... F, typename... A>
+inline void ext_launch(void (*kernel)(F...), dim3 grid, dim3 block, unsigned shmem, hipStream_t st, ProfEvents* ev,
+                       A&&... a) {
+    static_assert(sizeof...(F) >= sizeof...(A), "kernel argument count");
+    auto actuals = std::forward_as_tuple(a...);
+    ext_launch_conv(kernel, grid, block, shmem, st, ev, actuals, std::index_sequence_for<F...>{});
+}
 
-#define OFASR_LAUNCH(kernel, grid, block, shmem, stream, ...)                                \
-    do {                                                                                     \
-        ::ofasr::LaunchSite* _site = ::ofasr::launch_site<&kernel>(#kernel);                 \
-        __atomic_fetch_add(&_site->count, 1ull, __ATOMIC_RELAXED);                           \
-        void* _rec = ::ofasr::g_profile_on ? ::ofasr::prof_begin(_site, (stream)) : nullptr; \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                 \
-        if (_rec) ::ofasr::prof_end(_rec, (stream));                                         \
+#define OFASR_LAUNCH(kernel, grid, block, shmem, stream, ...)                                              \
+    do {                                                                                                   \
+        ::ofasr::LaunchSite* _site = ::ofasr::launch_site<&kernel>(#kernel);                               \
+        __atomic_fetch_add(&_site->count, 1ull, __ATOMIC_RELAXED);                                         \
+        ::ofasr::ProfEvents* _ev = ::ofasr::g_profile_on ? ::ofasr::prof_begin(_site) : nullptr;           \
+        if (_ev)                                                                                           \
+            ::ofasr::ext_launch(kernel, grid, block, shmem, stream, _ev, __VA_ARGS__);                     \
+        else                                                                                               \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                           \
     } while (0)
 
 #define OFASR_REQUIRE(cond, code, ...)      \

@@ -1,10 +1,35 @@
 #!/usr/bin/env python3
 """Aggregate a rocprofv3 kernel-trace CSV over the last N training steps (steps are delimited by the
 optimizer's multi_tensor_apply launches), optionally skipping the last `skip` steps (bench.py ends with 7 instrumented
-per-op steps for the roofline figure).  usage: trace_steps.py <kernel_trace.csv> [nsteps] [top] [skip]"""
+per-op steps for the roofline figure).  usage: trace_steps.py <kernel_trace.csv> [nsteps] [top] [skip] [summary.json key]
+With the last two arguments the per-kernel averages are also merged into summary.json under `key` (e.g. "bf16", "f32"),
+keyed by the kernel symbol as bench.py's kernel table spells it (no "void ofasr::", no parameter list): this is the
+file bench.py's roofline.trace_avg_us is read from."""
 import collections
 import csv
+import json
+import os
 import sys
+
+
+def site_name(n):
+    """rocprofv3's kernel name -> the launch-site name of the library (csrc/api.hip register_site)"""
+    depth, cut = 0, None
+    for i, ch in enumerate(n):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    if cut is not None:
+        n = n[:cut]
+    if n.startswith("void "):
+        n = n[5:]
+    if n.startswith("ofasr::"):
+        n = n[7:]
+    return n
 
 
 def main():
@@ -39,6 +64,17 @@ def main():
           "(union)  kernels/step=%.0f" % (nsteps, span / nsteps, busy / nsteps, union / 1e6 / nsteps, len(sel) / nsteps))
     for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
         print("%-96s n/step=%6.1f ms/step=%7.3f avg_us=%8.1f" % (n[:96], c / nsteps, t / 1e6 / nsteps, t / 1e3 / c))
+    if len(sys.argv) > 6:
+        out, key = sys.argv[5], sys.argv[6]
+        table = {}
+        if os.path.exists(out):
+            table = json.load(open(out))
+        table[key] = {"source": "rocprofv3 --kernel-trace of `bench.py --dtype %s`, last %d timed steps" % (key, nsteps),
+                      "wall_ms_per_step": round(span / nsteps, 3), "gpu_active_ms_per_step": round(union / 1e6 / nsteps, 3),
+                      "kernels": {site_name(n): {"avg_us": round(t / 1e3 / c, 2), "launches_per_step": round(c / nsteps, 2),
+                                                 "ms_per_step": round(t / 1e6 / nsteps, 4)}
+                                  for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+        json.dump(table, open(out, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

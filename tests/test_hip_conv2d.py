@@ -279,8 +279,9 @@ TRAIN_EPI_CASES = [
 def test_conv_layer_training_epilogue_statistics_vs_oracle(ora, case, dtype):
     """training-mode ConvLayer (reference ofa/layers.py:120-151): the conv kernel's epilogue takes the BatchNorm statistics
     (ofasr_conv2d_fwd_stat -> ofasr_bn_fwd_cp / ofasr_bn_finalize_cp + ofasr_pixel_shuffle2_bn).  Forward, running
-    statistics, and every gradient against the oracle's conv -> BN(batch statistics of the 16-bit conv output) -> act
-    chain in double; no statistics pass and no shuffle kernel in the forward."""
+    statistics, and every gradient (dX, dW, dgamma, dbeta through ofasr_bn_bwd_ps2 / ofasr_bn_act_bwd and the conv
+    backward kernels) against the oracle's conv -> BN(batch statistics of the 16-bit conv output) -> act chain in
+    double; no statistics pass and no shuffle kernel in the forward, no un-shuffle pass in the backward."""
     layers, C, ops = amd("layers"), amd("_C"), amd("ops")
     N, Cin, Cout, H, W, K, act = case
     r16 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dtype).float().numpy()
@@ -318,7 +319,6 @@ def test_conv_layer_training_epilogue_statistics_vs_oracle(ora, case, dtype):
     assert_close(layer.bn.running_var.cpu().numpy(), rv, 2e-3, 1e-4, "running_var")
     assert int(layer.bn.num_batches_tracked) == 1
 
-    # backward against the un-fused HIP path on the same layer (itself oracle-tested): same gradients
     dy = r16(det_uniform(tuple(y.shape), "cvt/dy%s" % (case,)))
     C.reset_launch_counts()
     y.backward(torch.from_numpy(dy).to(dtype).to(DEV))
@@ -327,6 +327,34 @@ def test_conv_layer_training_epilogue_statistics_vs_oracle(ora, case, dtype):
         assert C.launch_count("bn_bwd_reduce_ps_kernel") == 1 and C.launch_count("bn_bwd_apply_ps_kernel") == 1
     got = [xt.grad.float().cpu().numpy(), layer.conv.weight.grad.cpu().numpy(), layer.bn.weight.grad.cpu().numpy(),
            layer.bn.bias.grad.cpu().numpy()]
+
+    # (1) backward against the ORACLE, stage by stage on the 16-bit tensors each GPU stage read (reference
+    # ofa/layers.py:120-151 backward = PixelShuffle^-1 -> ReLU6 mask -> BatchNorm backward (batch statistics) -> conv
+    # backward).  The BN backward (ofasr_bn_bwd_ps2 / ofasr_bn_act_bwd) read the incoming gradient and the conv output
+    # the GPU stored; the conv backward read the 16-bit dyc that BN backward stored.
+    with torch.no_grad():
+        yc_gpu = ops.Conv2dFn.apply(torch.from_numpy(x).to(dtype).to(DEV), layer.conv.weight.detach()).float().cpu().numpy()
+    assert_close(yc_gpu, yc, rt, rt, "stored conv output")
+    dz = dy.astype(np.float32)
+    if act == "pixelshuffle":
+        dz = ora.pixel_unshuffle(dz, 2)
+    elif act == "relu6":
+        z_gpu, _, _ = ora.bn_fwd(yc_gpu, g, b, np.zeros(Cout, np.float32), np.ones(Cout, np.float32), True)
+        dz = dz * ((z_gpu > 0.0) & (z_gpu < 6.0))
+        # an element whose pre-activation sits within rounding of 0 or 6 may fall on the other side of the mask
+        edge = (np.abs(z_gpu) < 1e-3) | (np.abs(z_gpu - 6.0) < 1e-3)
+        assert edge.mean() < 1e-2
+    dyc_ref, dg_ref, db_ref = ora.bn_bwd_train(dz, yc_gpu, g)
+    big = lambda a_: max(float(np.abs(a_).max()), 1e-3)
+    assert_close(got[2], dg_ref, 2e-3, 2e-3 * big(dg_ref), "dgamma vs oracle")
+    assert_close(got[3], db_ref, 2e-3, 2e-3 * big(db_ref), "dbeta vs oracle")
+    dx_ref, dw_ref = ora.conv2d_bwd(r16(dyc_ref), x, r16(w))
+    # dx / dw: the GPU's stored dyc is the oracle's up to one 16-bit rounding per element (relative rt / 4), which the
+    # convolution sums over Cout * K * K (dx) and N * H * W (dw) terms with random signs
+    assert_close(got[0], dx_ref, rt, rt * big(dx_ref), "dx vs oracle")
+    assert_close(got[1], dw_ref, rt, rt * big(dw_ref), "dw vs oracle")
+
+    # (2) and against the un-fused HIP path on the same layer (conv -> statistics pass -> apply -> shuffle kernel)
     for p in (layer.conv.weight, layer.bn.weight, layer.bn.bias):
         p.grad = None
     with torch.no_grad():

@@ -4,7 +4,7 @@ MI355X_MICROARCH.md prescribes) into per-kernel HBM bytes per launch.
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out/fetch -- python3 bench.py ...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d out/write -- python3 bench.py ...
-    python tools/pmc_traffic.py out/fetch out/write profiles/pmc_traffic.json
+    python tools/pmc_traffic.py out/fetch out/write profiles/pmc_traffic.json [--merge]
 
 Units / corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B/lane) -> doubled;
@@ -84,6 +84,11 @@ def main():
         write_b = 1024.0 * w / n
         table[k] = {"launches": n, "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
                     "hbm_bytes_per_launch": fetch_b + write_b}
+    if len(sys.argv) > 4 and sys.argv[4] == "--merge" and os.path.exists(out):
+        # a second command's passes (the fp32 step, config 5) added to the table of the first: kernels the first
+        # command already measured keep its numbers
+        old = json.load(open(out))
+        table = dict(list(table.items()) + list(old.items()))
     with open(out, "w") as f:
         json.dump(table, f, indent=1, sort_keys=True)
     for k, v in sorted(table.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:25]:
