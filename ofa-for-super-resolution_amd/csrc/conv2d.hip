@@ -699,6 +699,10 @@ static int launch_conv2d_wgrad(const char* name, const void* dy, const void* x, 
 }
 
 static int conv_stat_units(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K) {
+    if (conv_thin_out_supported(Cout, Cin, K, W, OFASR_BF16, nullptr, nullptr))   // the head: one partial per workgroup
+        return conv_thin_out_units(N, Cout, Cin, H, W, OFASR_BF16);
+    if (conv_thin_in_supported(Cin, Cout, K, W, OFASR_BF16, nullptr, nullptr))    // the stem
+        return conv_thin_in_units(N, Cin, Cout, H, W, OFASR_BF16);
     const CvPlan p = cv_plan(Cin, Cout, K, 0, N, H, W);
     const int wp = p.th / 2;     // waves along the pixel rows of a tile: 2 rows each
     return (int)(N * cdiv(W, CV_TW) * cdiv(H, p.th) * wp);
@@ -719,6 +723,23 @@ static int conv2d_entry(const char* name, const void* x, const float* w, void* y
     OFASR_REQUIRE(ws && ws_bytes >= p.img_bytes, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", name,
                   ws_bytes, p.img_bytes);
     hipStream_t st = as_stream(stream);
+    {
+        // a 3-channel result (the head's forward, the stem's input gradient): csrc/conv_thin.hip
+        const int64_t Ct = dgrad ? Cin : Cout, Cw = dgrad ? Cout : Cin;
+        if (conv_thin_out_supported(Ct, Cw, K, W, dtype, x, y)) {
+            if (so.partial)
+                OFASR_REQUIRE(!dgrad && so.P == conv_thin_out_units(N, Ct, Cw, H, W, dtype), OFASR_ERR_INVALID_ARG,
+                              "%s: statistics unit count %d does not match the launch", name, so.P);
+            return conv_thin_out(x, w, y, N, Ct, Cw, H, W, K, dtype, dgrad, so, stream);
+        }
+        // a 3-channel operand (the stem's forward, the head's input gradient)
+        if (conv_thin_in_supported(Cw, Ct, K, W, dtype, x, y)) {
+            if (so.partial)
+                OFASR_REQUIRE(!dgrad && so.P == conv_thin_in_units(N, Cw, Ct, H, W, dtype), OFASR_ERR_INVALID_ARG,
+                              "%s: statistics unit count %d does not match the launch", name, so.P);
+            return conv_thin_in(x, w, y, N, Cw, Ct, H, W, K, dtype, dgrad, so, stream);
+        }
+    }
     if (so.partial)
         OFASR_REQUIRE(!dgrad && so.P == conv_stat_units(N, Cin, Cout, H, W, K), OFASR_ERR_INVALID_ARG,
                       "%s: statistics unit count %d does not match the launch", name, so.P);

@@ -312,6 +312,14 @@ static int conv2d_f32_entry(const char* name, const void* x, const float* w, voi
     const size_t need = ofasr_conv2d_f32_workspace(Cin, Cout, K, dgrad);
     OFASR_REQUIRE(ws && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 15) == 0, OFASR_ERR_WORKSPACE,
                   "%s: workspace %zu B < required %zu B (or not 16-byte aligned)", name, ws_bytes, need);
+    {
+        // a 3-channel result (the head's forward, the stem's input gradient): csrc/conv_thin.hip
+        const int64_t Ct = dgrad ? Cin : Cout, Cw = dgrad ? Cout : Cin;
+        if (conv_thin_out_supported(Ct, Cw, K, W, OFASR_F32, x, y))
+            return conv_thin_out(x, w, y, N, Ct, Cw, H, W, K, OFASR_F32, dgrad, StatOut{nullptr, 0}, stream);
+        if (conv_thin_in_supported(Cw, Ct, K, W, OFASR_F32, x, y))
+            return conv_thin_in(x, w, y, N, Cw, Ct, H, W, K, OFASR_F32, dgrad, StatOut{nullptr, 0}, stream);
+    }
     const int M = (int)(dgrad ? Cin : Cout), Kdim = (int)(dgrad ? Cout : Cin), Mpad = cf_mpad(M);
     const int nkc = (int)cdiv(Kdim, CF_KC);
     hipStream_t st = as_stream(stream);

@@ -345,6 +345,19 @@ int bn_fwd_cp(const void* x, const void* residual, void* y, const float2* partia
               const float* beta, float* running_mean, float* running_var, double momentum, double eps, int training,
               float* stats, int64_t N, int64_t C, int64_t HW, int act, int dtype, void* stream);
 
+// conv_thin.hip: the static convs with a 3-channel side (head / stem); conv2d.hip and conv2d_f32.hip route to them.
+// "out": the THIN tensor is the result (forward with Cout thin, input gradient with Cin thin);
+// "in": the THIN tensor is the operand; dgrad = 1 reads the [Cout][Cin][K][K] weights transposed and mirrored.
+bool conv_thin_enabled();
+bool conv_thin_out_supported(int64_t Ct, int64_t Cw, int K, int64_t W, int dtype, const void* x, const void* y);
+int conv_thin_out_units(int64_t N, int64_t Ct, int64_t Cw, int64_t H, int64_t W, int dtype);
+int conv_thin_out(const void* x, const float* w, void* y, int64_t N, int64_t Ct, int64_t Cw, int64_t H, int64_t W, int K,
+                  int dtype, int dgrad, StatOut so, void* stream);
+bool conv_thin_in_supported(int64_t Ct, int64_t Cw, int K, int64_t W, int dtype, const void* x, const void* y);
+int conv_thin_in_units(int64_t N, int64_t Ct, int64_t Cw, int64_t H, int64_t W, int dtype);
+int conv_thin_in(const void* x, const float* w, void* y, int64_t N, int64_t Ct, int64_t Cw, int64_t H, int64_t W, int K,
+                 int dtype, int dgrad, StatOut so, void* stream);
+
 // internal (not exported) variants used by mbconv.hip; they return OFASR_ERR_UNSUPPORTED (and launch nothing) when
 // the vector / aligned 16-bit kernels that implement the fused read do not apply to the shape.
 bool dwconv_xf_supported(const void* x, const void* y, int64_t H, int64_t W, int K, int dtype);

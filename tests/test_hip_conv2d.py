@@ -10,6 +10,17 @@ from detfill import det_uniform
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
+
+def _n_conv(C, f32=False):
+    """forward / input-gradient launches of the static-conv kernels: the implicit-GEMM kernel of the dtype, or -- for a
+    3-channel side (stem / head) -- the thin-side kernels of csrc/conv_thin.hip"""
+    return C.launch_count("conv_f32_kernel" if f32 else "conv_igemm_kernel") + C.launch_count("ct_out_kernel") + \
+        C.launch_count("ct_in_kernel")
+
+
+def _n_wgrad(C, f32=False):
+    return C.launch_count("conv_f32_wgrad_kernel" if f32 else "conv_wgrad_kernel") + C.launch_count("ct_wg_kernel")
+
 CASES = [
     # N, Cin, Cout, H, W, K
     (1, 64, 128, 6, 64, 5),     # one 128-row slab, 3 row tiles
@@ -117,7 +128,7 @@ def test_conv2d_ragged_width_vs_oracle(ora, case):
     xt = torch.from_numpy(x).to(dtype).to(DEV).requires_grad_(True)
     C.reset_launch_counts()
     y = ops.conv2d(xt, conv)
-    assert C.launch_count("conv_igemm_kernel") == 1 and tuple(y.shape) == (N, Cout, H, W)
+    assert _n_conv(C) == 1 and tuple(y.shape) == (N, Cout, H, W)
     y_ref = ora.conv2d_fwd(x, r16(w))
     assert_close(y.detach().float().cpu().numpy(), y_ref, 1e-2, 1e-2, "y")
     y.backward(torch.from_numpy(dy).to(dtype).to(DEV))
@@ -148,11 +159,11 @@ def test_conv2d_fp32_vs_oracle(ora, case):
         y = ops.conv2d(xt, conv)
     finally:
         ops.CONV_FORCE_HIP = was
-    assert C.launch_count("conv_f32_kernel") == 1 and y.dtype == torch.float32
+    assert _n_conv(C, True) == 1 and y.dtype == torch.float32
     y_ref = ora.conv2d_fwd(x, w)
     assert_close(y.detach().cpu().numpy(), y_ref, 5e-5, 5e-6, "y")
     y.backward(torch.from_numpy(dy).to(DEV))
-    assert C.launch_count("conv_f32_kernel") == 2 and C.launch_count("conv_f32_wgrad_kernel") == 1
+    assert _n_conv(C, True) == 2 and _n_wgrad(C, True) == 1
     dx_ref, dw_ref = ora.conv2d_bwd(dy, x, w)
     scale = float(np.sqrt(Cout * K * K / max(Cin * K * K, 1)))
     assert_close(xt.grad.cpu().numpy(), dx_ref, 5e-5, 5e-6 * max(1.0, scale), "dx")
@@ -271,6 +282,7 @@ TRAIN_EPI_CASES = [
     (3, 3, 64, 8, 72, 5, "relu6"),            # stem: tiles cut by the right border (72 = 64 + 8)
     (2, 64, 64, 5, 128, 5, None),
     (2, 64, 128, 9, 32, 3, "relu6"),          # odd H: the last row of the last 2-row strip is outside the image
+    (2, 64, 3, 12, 136, 5, None),             # head: 3 output channels (csrc/conv_thin.hip), two column strips
 ]
 
 
@@ -299,7 +311,7 @@ def test_conv_layer_training_epilogue_statistics_vs_oracle(ora, case, dtype):
     C.reset_launch_counts()
     y = layer(xt)
     table = C.launch_table()
-    assert C.launch_count("conv_igemm_kernel") == 1 and C.launch_count("bn_stats_kernel") == 0, table
+    assert _n_conv(C) == 1 and C.launch_count("bn_stats_kernel") == 0, table
     assert C.launch_count("ps_r2_kernel") == 0 and C.launch_count("ps_generic") == 0, table
     assert C.launch_count("ps_r2_bn_kernel") == (1 if act == "pixelshuffle" else 0), table
 
