@@ -833,7 +833,13 @@ OFASR_EXPORT int ofasr_conv2d_dgrad(const void* dy, const float* w, void* dx, in
 
 OFASR_EXPORT size_t ofasr_conv2d_wgrad_workspace(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || !(K == 3 || K == 5)) return 0;
-    return cv_wg_plan(N, Cin, Cout, H, W, K).part_bytes;
+    size_t need = cv_wg_plan(N, Cin, Cout, H, W, K).part_bytes;
+    const int64_t Ct = Cin < Cout ? Cin : Cout, Cw = Cin < Cout ? Cout : Cin;
+    if (conv_thin_wgrad_supported(Ct, Cw, K, H, W, OFASR_BF16, nullptr, nullptr)) {   // the head / stem: csrc/conv_thin.hip
+        const size_t thin = conv_thin_wgrad_workspace(N, Ct, Cw, H, W, K, OFASR_BF16);
+        need = thin > need ? thin : need;
+    }
+    return need;
 }
 
 OFASR_EXPORT int ofasr_conv2d_wgrad(const void* dy, const void* x, float* dw, int64_t N, int64_t Cin, int64_t Cout,
@@ -848,6 +854,11 @@ OFASR_EXPORT int ofasr_conv2d_wgrad(const void* dy, const void* x, float* dw, in
     OFASR_REQUIRE(W % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0,
                   OFASR_ERR_UNSUPPORTED, "%s: needs W %% 8 == 0 and 16-byte aligned tensors", name);
     OFASR_REQUIRE(N * H * W <= (1LL << 30), OFASR_ERR_UNSUPPORTED, "%s: too large", name);
+    {
+        const int64_t Ct = Cin < Cout ? Cin : Cout, Cw = Cin < Cout ? Cout : Cin;
+        if (conv_thin_wgrad_supported(Ct, Cw, K, H, W, dtype, dy, x))
+            return conv_thin_wgrad(dy, x, dw, N, Cin, Cout, H, W, K, dtype, workspace, workspace_bytes, stream);
+    }
     const CvWgPlan p = cv_wg_plan(N, Cin, Cout, H, W, K);
     OFASR_REQUIRE(workspace && workspace_bytes >= p.part_bytes, OFASR_ERR_WORKSPACE,
                   "%s: workspace %zu B < required %zu B", name, workspace_bytes, p.part_bytes);

@@ -353,7 +353,13 @@ OFASR_EXPORT int ofasr_conv2d_f32_dgrad(const void* dy, const float* w, void* dx
 
 OFASR_EXPORT size_t ofasr_conv2d_f32_wgrad_workspace(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || !(K == 3 || K == 5)) return 0;
-    return (size_t)cf_nsplit(N, Cin, Cout, H, W) * Cout * Cin * K * K * sizeof(float);
+    size_t need = (size_t)cf_nsplit(N, Cin, Cout, H, W) * Cout * Cin * K * K * sizeof(float);
+    const int64_t Ct = Cin < Cout ? Cin : Cout, Cw = Cin < Cout ? Cout : Cin;
+    if (conv_thin_wgrad_supported(Ct, Cw, K, H, W, OFASR_F32, nullptr, nullptr)) {   // the head / stem: csrc/conv_thin.hip
+        const size_t thin = conv_thin_wgrad_workspace(N, Ct, Cw, H, W, K, OFASR_F32);
+        need = thin > need ? thin : need;
+    }
+    return need;
 }
 
 OFASR_EXPORT int ofasr_conv2d_f32_wgrad(const void* dy, const void* x, float* dw, int64_t N, int64_t Cin, int64_t Cout,
@@ -366,6 +372,11 @@ OFASR_EXPORT int ofasr_conv2d_f32_wgrad(const void* dy, const void* x, float* dw
     const size_t need = ofasr_conv2d_f32_wgrad_workspace(N, Cin, Cout, H, W, K);
     OFASR_REQUIRE(workspace && workspace_bytes >= need, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", name,
                   workspace_bytes, need);
+    {
+        const int64_t Ct = Cin < Cout ? Cin : Cout, Cw = Cin < Cout ? Cout : Cin;
+        if (conv_thin_wgrad_supported(Ct, Cw, K, H, W, OFASR_F32, dy, x))
+            return conv_thin_wgrad(dy, x, dw, N, Cin, Cout, H, W, K, OFASR_F32, workspace, workspace_bytes, stream);
+    }
     const int nsplit = cf_nsplit(N, Cin, Cout, H, W);
     const int tiles_x = (int)cdiv(W, CF_TW), tiles_y = (int)cdiv(H, CF_WG_TH);
     const int ntiles = (int)(N * tiles_x * tiles_y);

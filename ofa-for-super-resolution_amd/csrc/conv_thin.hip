@@ -629,6 +629,212 @@ __global__ __launch_bounds__(CT_IN_THREADS) void ct_in_kernel(const T* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// thin WEIGHT GRADIENT:  G[(t, sxi)][c][syi] = sum over the block's pixels of Thin[t][y - syi + p][x - sxi + p] * Wide[c][y][x]
+//
+// k = 32 consecutive pixels of a row.  B (wide): lane (channel l16 of a 16-channel tile, group kg) requests the 8 pixels
+// xb + 8 kg .. +7 of its channel row straight from global memory -- 16 bytes (two requests in fp32), no LDS; the requests
+// of an item are issued CT_WPD items ahead.  A (thin): lane (row m = t * k + sxi, group kg) reads the same 8 pixels shifted
+// by sxi - p from the LDS image of the segment's thin rows (16-bit: five dwords and a funnel shift).  A wave walks the
+// items (row, 32-pixel chunk) i = wave, wave + 8, ... of its block with the k x NT accumulator tiles of ALL kernel rows
+// in registers; at the end the waves add their tiles into one LDS slab in wave order and the block writes the slab;
+// ct_wg_reduce_kernel sums the slabs in block order into the parameter's gradient (deterministic, no atomics).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int CT_WG_THREADS = 512;
+constexpr int CT_WPD = 3;          // items whose wide fragments are in flight ahead of the one being multiplied
+
+struct CtWgGeom {
+    int N, H, W, Ct, Cw;
+    int segs, RS;          // row segments per image, rows per segment
+    int nchunks;           // 32-pixel chunks per row
+    int trow;              // bytes per (row, channel) of the thin LDS image: (W + 16 + pad) elements
+};
+
+template <typename T, int K, int NT>
+__global__ __launch_bounds__(CT_WG_THREADS) void ct_wg_kernel(const T* __restrict__ Thin, const T* __restrict__ Wide,
+                                                              float* __restrict__ slabs, CtWgGeom g) {
+    constexpr bool is16 = CtElem<T>::is16;
+    constexpr int EPC = CtElem<T>::EPC, P = K / 2, ES = (int)sizeof(T);
+    constexpr int BV = is16 ? 1 : 2;                  // 16-byte requests per lane and channel tile
+    constexpr int HALO = 8;                           // thin image: column index = column + HALO
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg = blockIdx.x % g.segs, n = blockIdx.x / g.segs;
+    const int ys = seg * g.RS, ye = min(ys + g.RS, g.H);
+    const int nheld = ye - ys + K - 1;                // thin rows ys - P .. ye - 1 + P
+    const long long plane = (long long)g.H * g.W;
+    char* thin = smem;
+
+    // ---- the thin rows of the segment -> LDS: [held row][t][trow], zero outside the image --------------------------
+    {
+        const T* Tn = Thin + (long long)n * g.Ct * plane;
+        const int cpr = g.trow / 16;                  // 16-byte chunks per (row, channel)
+        const int total = nheld * g.Ct * cpr;
+        for (int id0 = 0; id0 < total; id0 += 4 * CT_WG_THREADS) {
+            ct_u32x4 v[4];
+            int off[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int id = min(id0 + u * CT_WG_THREADS + tid, total - 1);
+                const int jc = id % cpr, rc = id / cpr;
+                const int t = rc % g.Ct, row = ys - P + rc / g.Ct;
+                const int col = jc * EPC - HALO;
+                const bool ok = row >= 0 && row < g.H && col >= 0 && col < g.W;
+                const long long src = (long long)t * plane + (long long)(ok ? row : 0) * g.W + (ok ? col : 0);
+                v[u] = *reinterpret_cast<const ct_u32x4*>(Tn + src);
+                if (!ok) v[u] = ct_u32x4{0u, 0u, 0u, 0u};
+                off[u] = rc * g.trow + jc * 16;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<ct_u32x4*>(thin + off[u]) = v[u];
+        }
+    }
+    __syncthreads();
+
+    const int l16 = lane & 15, kg = lane >> 4;
+    const bool mvalid = l16 < g.Ct * K;
+    const int mt = mvalid ? l16 / K : 0, msx = l16 % K;          // this lane's A row: thin channel, column shift index
+    // A addressing: first element = column xb + 8 kg - (msx - P), image index + HALO
+    const int ja = 8 * kg - msx + P + HALO;                      // + xb
+    const int a_lane = mt * g.trow + (is16 ? (ja & ~1) * 2 : ja * 4);
+    const int sh = (ja & 1) * 16;
+    const T* Wn = Wide + (long long)n * g.Cw * plane;
+    const long long b_lane = (long long)l16 * plane + 8 * kg;     // + tile * 16 * plane + row * W + xb
+
+    ct_f32x4 acc[K][NT];
+#pragma unroll
+    for (int sy = 0; sy < K; ++sy)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[sy][nt] = ct_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nitems = (ye - ys) * g.nchunks;
+    const int per_wave = (nitems + 7) / 8;
+    const int trips = (per_wave + CT_WPD - 1) / CT_WPD;
+    ct_u32x4 bst[CT_WPD][NT][BV];
+    auto request = [&](int d, int it) {
+        const int i = min(wave + 8 * it, nitems - 1);            // items beyond the block's last repeat it (and contribute zero)
+        const int row = ys + i / g.nchunks, xb = 32 * (i % g.nchunks);
+        const bool ok = xb + 8 * kg < g.W;                        // (W % 8 == 0: the 8 pixels are all in or all out)
+        const T* src = Wn + b_lane + (long long)row * g.W + (ok ? xb : 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < BV; ++q)
+                bst[d][nt][q] = *reinterpret_cast<const ct_u32x4*>(src + (long long)nt * 16 * plane + q * 4);
+    };
+#pragma unroll
+    for (int d = 0; d < CT_WPD - 1; ++d) request(d, d);
+
+    for (int tr = 0; tr < trips; ++tr) {
+#pragma unroll
+        for (int d = 0; d < CT_WPD; ++d) {
+            const int it = tr * CT_WPD + d;
+            request((d + CT_WPD - 1) % CT_WPD, it + CT_WPD - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int i = wave + 8 * it;
+            const bool live = i < nitems;
+            const int ic = min(i, nitems - 1);
+            const int rrel = ic / g.nchunks, xb = 32 * (ic % g.nchunks);
+            const bool ok = live && xb + 8 * kg < g.W;
+            const char* abase = thin + a_lane + xb * ES;
+            if constexpr (is16) {
+                ct_s16x8 bf[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    ct_u32x4 v = bst[d][nt][0];
+                    if (!ok) v = ct_u32x4{0u, 0u, 0u, 0u};
+                    bf[nt] = __builtin_bit_cast(ct_s16x8, v);
+                }
+#pragma unroll
+                for (int sy = 0; sy < K; ++sy) {
+                    // thin row y - (sy - P) is held row (y - ys) + K - 1 - sy
+                    const unsigned int* q = reinterpret_cast<const unsigned int*>(abase + (rrel + K - 1 - sy) * g.Ct * g.trow);
+                    unsigned int dw[5];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) dw[j] = q[j];
+                    ct_u32x4 pk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pk[j] = mvalid ? __builtin_amdgcn_alignbit(dw[j + 1], dw[j], sh) : 0u;
+                    const ct_s16x8 af = __builtin_bit_cast(ct_s16x8, pk);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[sy][nt] = ct_mma16<T>(af, bf[nt], acc[sy][nt]);
+                }
+            } else {
+                float bv[NT][8];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bv[nt][j] = ok ? __uint_as_float(bst[d][nt][j >> 2][j & 3]) : 0.f;
+#pragma unroll
+                for (int sy = 0; sy < K; ++sy) {
+                    const float* q = reinterpret_cast<const float*>(abase + (rrel + K - 1 - sy) * g.Ct * g.trow);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float av = mvalid ? q[j] : 0.f;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[sy][nt] = ct_mma32(av, bv[nt][j], acc[sy][nt]);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- the waves' tiles -> one slab [sy][nt][m = 4 kg + i][c = l16], added in wave order ---------------------------
+    __syncthreads();
+    float* slab = reinterpret_cast<float*>(smem);   // the thin image is not needed any more
+    for (int w = 0; w < CT_WG_THREADS / 64; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int sy = 0; sy < K; ++sy)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float* p = slab + ((sy * NT + nt) * 16 + 4 * kg + i) * 16 + l16;
+                        *p = (w == 0 ? 0.f : *p) + acc[sy][nt][i];
+                    }
+        }
+        __syncthreads();
+    }
+    float* dst = slabs + (long long)blockIdx.x * (K * NT * 256);
+    for (int i = tid; i < K * NT * 256; i += CT_WG_THREADS) dst[i] = slab[i];
+}
+
+// dw[co][ci][ky][kx] = sum over the blocks' slabs.  role 0 (head: thin = dY, wide = X): co = t, ci = c, (ky, kx) = (sy, sx);
+// role 1 (stem: thin = X, wide = dY): ci = t, co = c, (ky, kx) = (k - 1 - sy, k - 1 - sx).
+// A block folds 16 consecutive slab elements: thread (element tid & 15, group tid >> 4) adds the slabs group, group + 16, ...
+// in that order with all its requests in flight, then the 16 groups are added in group order (fixed order: deterministic).
+template <int K>
+__global__ __launch_bounds__(256) void ct_wg_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int nslabs,
+                                                           int Ct, int Cw, int NT, int role) {
+    __shared__ float red[256];
+    const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;                 // slab element ((sy * NT + nt) * 16 + m) * 16 + c16
+    const long long stride = (long long)K * NT * 256;
+    float s = 0.f;
+    for (int b0 = grp; b0 < nslabs; b0 += 16 * 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = slabs[(long long)min(b0 + 16 * j, nslabs - 1) * stride + e];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += b0 + 16 * j < nslabs ? v[j] : 0.f;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[16 * j + el];
+        const int c16 = e & 15, m = (e >> 4) & 15, nt = (e >> 8) % NT, sy = (e >> 8) / NT;
+        if (m < Ct * K) {
+            const int tch = m / K, sx = m % K, c = 16 * nt + c16;
+            const int ky = role ? K - 1 - sy : sy, kx = role ? K - 1 - sx : sx;
+            const int co = role ? c : tch, ci = role ? tch : c, Cin = role ? Ct : Cw;
+            dw[((co * Cin + ci) * K + ky) * K + kx] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
 static int ct_num_cus() {
@@ -725,6 +931,88 @@ int conv_thin_in(const void* x, const float* w, void* y, int64_t N, int64_t Ct, 
 #undef OFASR_CTI_T
 #undef OFASR_CTI
     return check_launch("conv_thin_in");
+}
+
+static CtWgGeom ct_wg_geom(int64_t N, int64_t Ct, int64_t Cw, int64_t H, int64_t W, int es) {
+    CtWgGeom g{};
+    g.N = (int)N; g.H = (int)H; g.W = (int)W; g.Ct = (int)Ct; g.Cw = (int)Cw;
+    g.nchunks = (int)cdiv(W, 32);
+    // bytes per (row, channel): columns -8 .. 32 * nchunks + 8 + 2 (the funnel shift reads one dword further)
+    g.trow = (int)((32 * g.nchunks + 24) * es + 15) / 16 * 16;
+    int64_t segs = cdiv(ct_num_cus(), N);
+    int64_t RS = cdiv(H, segs < 1 ? 1 : segs);
+    // a block's fixed costs (thin image, the waves' fold, its 20 KB slab) want >= 8 items per wave
+    const int64_t min_rows = cdiv(64, g.nchunks);
+    if (RS < min_rows) RS = H < min_rows ? H : min_rows;
+    while (RS > 4 && (RS + 4) * Ct * g.trow > 96 * 1024) RS = (RS + 1) / 2;
+    g.RS = (int)RS;
+    g.segs = (int)cdiv(H, RS);
+    return g;
+}
+
+bool conv_thin_wgrad_supported(int64_t Ct, int64_t Cw, int K, int64_t H, int64_t W, int dtype, const void* a, const void* b) {
+    if (!conv_thin_enabled() || !(K == 3 || K == 5) || Ct * K > 16 || Ct > 4 || !(Cw == 32 || Cw == 64)) return false;
+    const int es = dtype == OFASR_F32 ? 4 : 2;
+    if (W % (16 / es) != 0 || W > 1024) return false;
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+}
+
+size_t conv_thin_wgrad_workspace(int64_t N, int64_t Ct, int64_t Cw, int64_t H, int64_t W, int K, int dtype) {
+    const CtWgGeom g = ct_wg_geom(N, Ct, Cw, H, W, dtype == OFASR_F32 ? 4 : 2);
+    return (size_t)g.N * g.segs * K * (Cw / 16) * 256 * sizeof(float);
+}
+
+template <typename T, int K, int NT>
+static void ct_wg_launch(const void* thin, const void* wide, float* slabs, const CtWgGeom& g, hipStream_t st) {
+    size_t lds = (size_t)(g.RS + K - 1) * g.Ct * g.trow;
+    const size_t slab = (size_t)K * NT * 256 * sizeof(float);
+    if (lds < slab) lds = slab;
+    static bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ct_wg_kernel<T, K, NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        return true;
+    }();
+    (void)attr;
+    OFASR_LAUNCH((ct_wg_kernel<T, K, NT>), dim3((unsigned)(g.N * g.segs)), dim3(CT_WG_THREADS), lds, st, (const T*)thin,
+                 (const T*)wide, slabs, g);
+}
+
+// dw [Cout][Cin][K][K] of a conv with a thin side.  role 0: Cout thin (thin = dy, wide = x); role 1: Cin thin (thin = x, wide = dy)
+int conv_thin_wgrad(const void* dy, const void* x, float* dw, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K,
+                    int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    const int role = Cin < Cout ? 1 : 0;
+    const int64_t Ct = role ? Cin : Cout, Cw = role ? Cout : Cin;
+    const void* thin = role ? x : dy;
+    const void* wide = role ? dy : x;
+    const size_t need = conv_thin_wgrad_workspace(N, Ct, Cw, H, W, K, dtype);
+    OFASR_REQUIRE(workspace && workspace_bytes >= need, OFASR_ERR_WORKSPACE, "conv_thin_wgrad: workspace %zu B < required %zu B",
+                  workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    const CtWgGeom g = ct_wg_geom(N, Ct, Cw, H, W, dtype == OFASR_F32 ? 4 : 2);
+    const double es = dtype == OFASR_F32 ? 4.0 : 2.0;
+    prof_note(es * (double)N * (double)H * (double)W * (double)(Ct + Cw), 2.0 * (double)N * (double)H * (double)W * (double)Ct * (double)Cw * K * K);
+#define OFASR_CTW(TT, KK, NTT) ct_wg_launch<TT, KK, NTT>(thin, wide, (float*)workspace, g, st);
+#define OFASR_CTW_T(TT)                                                   \
+    if (K == 5) {                                                         \
+        if (Cw == 64) OFASR_CTW(TT, 5, 4) else OFASR_CTW(TT, 5, 2)        \
+    } else {                                                              \
+        if (Cw == 64) OFASR_CTW(TT, 3, 4) else OFASR_CTW(TT, 3, 2)        \
+    }
+    if (dtype == OFASR_BF16) { OFASR_CTW_T(bf16_t) }
+    else if (dtype == OFASR_F16) { OFASR_CTW_T(f16_t) }
+    else { OFASR_CTW_T(float) }
+#undef OFASR_CTW_T
+#undef OFASR_CTW
+    int rc = check_launch("conv_thin_wgrad");
+    if (rc) return rc;
+    const unsigned rblocks = (unsigned)(K * (Cw / 16) * 256 / 16);
+    if (K == 5)
+        OFASR_LAUNCH(ct_wg_reduce_kernel<5>, dim3(rblocks), dim3(256), 0, st, (const float*)workspace, dw, g.N * g.segs, (int)Ct,
+                     (int)Cw, (int)(Cw / 16), role);
+    else
+        OFASR_LAUNCH(ct_wg_reduce_kernel<3>, dim3(rblocks), dim3(256), 0, st, (const float*)workspace, dw, g.N * g.segs, (int)Ct,
+                     (int)Cw, (int)(Cw / 16), role);
+    return check_launch("conv_thin_wgrad_reduce");
 }
 
 bool conv_thin_out_supported(int64_t Ct, int64_t Cw, int K, int64_t W, int dtype, const void* x, const void* y) {

@@ -353,6 +353,10 @@ bool conv_thin_out_supported(int64_t Ct, int64_t Cw, int K, int64_t W, int dtype
 int conv_thin_out_units(int64_t N, int64_t Ct, int64_t Cw, int64_t H, int64_t W, int dtype);
 int conv_thin_out(const void* x, const float* w, void* y, int64_t N, int64_t Ct, int64_t Cw, int64_t H, int64_t W, int K,
                   int dtype, int dgrad, StatOut so, void* stream);
+bool conv_thin_wgrad_supported(int64_t Ct, int64_t Cw, int K, int64_t H, int64_t W, int dtype, const void* a, const void* b);
+size_t conv_thin_wgrad_workspace(int64_t N, int64_t Ct, int64_t Cw, int64_t H, int64_t W, int K, int dtype);
+int conv_thin_wgrad(const void* dy, const void* x, float* dw, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K,
+                    int dtype, void* workspace, size_t workspace_bytes, void* stream);
 bool conv_thin_in_supported(int64_t Ct, int64_t Cw, int K, int64_t W, int dtype, const void* x, const void* y);
 int conv_thin_in_units(int64_t N, int64_t Ct, int64_t Cw, int64_t H, int64_t W, int dtype);
 int conv_thin_in(const void* x, const float* w, void* y, int64_t N, int64_t Ct, int64_t Cw, int64_t H, int64_t W, int K,

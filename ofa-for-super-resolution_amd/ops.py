@@ -832,15 +832,16 @@ def _conv_f32_policy(cin, cout, k, H, W):
 
     Measured on MI355X at the S4 shapes (tools/kbench.py --dtype f32, profiles/r02_kbench_f32.txt): the wide convs'
     forward / input gradient run at the vendor kernels' rate (120 against 122 TFLOP/s on 64 -> 256 @128x128, 76 % of
-    the fp32 matrix peak); the weight gradient (67 against 119) and the 3-channel stem / head convs (a 32-row matrix tile
-    for 3 channels) are slower -- the fp32 training step is 26 ms with the own kernels everywhere and 22.4 ms with the
-    vendor's weight gradients and 3-channel convs.  OFASR_CONV_F32_VENDOR=1 selects that mix for regular training
-    shapes; it is not the default because the vendor library's per-shape kernel search costs minutes on a fresh
+    the fp32 matrix peak); the wide convs' weight gradient (67 against 119) is slower.  The 3-channel stem / head convs
+    run on the thin-side kernels of csrc/conv_thin.hip (round 3: head forward 1752 -> 195 us, weight gradient 1656 ->
+    136 us; the vendor's were ~1100 us each).  OFASR_CONV_F32_VENDOR=1 selects the vendor's weight gradient for the wide
+    convs of regular training shapes; it is not the default because the vendor library's per-shape kernel search costs minutes on a fresh
     machine (260 s for the five shapes of one bench.py run) and because ragged Set14 sizes would search per image."""
     if not CONV_F32_VENDOR or CONV_FORCE_HIP or W % 8 != 0 or H % 2 != 0:
         return True, True, True
-    wide = min(cin, cout) >= 16
-    return wide, wide, False
+    if min(cin, cout) <= 4:     # the 3-channel stem / head: csrc/conv_thin.hip (10x the vendor kernels' rate, round 3)
+        return True, True, True
+    return True, True, False
 
 
 class Conv2dF32Fn(Function):

@@ -245,7 +245,8 @@ def test_conv_layer_inference_one_kernel_vs_oracle(ora, case, dtype):
 
 def test_conv2d_fp32_policy_routes_and_matches_oracle(ora):
     """_conv_f32_policy: a regular training shape takes the own forward / input gradient and the vendor weight gradient;
-    a 3-channel conv the vendor kernels; a ragged width the own kernels for all three -- same results either way."""
+    a 3-channel conv the thin-side kernels (csrc/conv_thin.hip) for all three; a ragged width the own kernels for all
+    three -- same results either way."""
     ops, C = amd("ops"), amd("_C")
     was, ops.CONV_F32_VENDOR = ops.CONV_F32_VENDOR, True     # the opt-in mix (OFASR_CONV_F32_VENDOR=1); default: own kernels
     try:
@@ -269,6 +270,9 @@ def _policy_cases(ora, ops, C):
         y.backward(torch.from_numpy(dy).to(DEV))
         assert C.launch_count("conv_f32_kernel") == want[0] + want[1], (case, C.launch_table())
         assert C.launch_count("conv_f32_wgrad_kernel") == want[2], (case, C.launch_table())
+        if min(Cin, Cout) <= 4:
+            assert C.launch_count("ct_out_kernel") == 1 and C.launch_count("ct_in_kernel") == 1 and \
+                C.launch_count("ct_wg_kernel") == 1, (case, C.launch_table())
         dx_ref, dw_ref = ora.conv2d_bwd(dy, x, w)
         assert_close(y.detach().cpu().numpy(), ora.conv2d_fwd(x, w), 5e-5, 5e-6, "y")
         scale = float(np.sqrt(Cout * K * K / max(Cin * K * K, 1)))
