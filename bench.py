@@ -92,6 +92,7 @@ class TrainWorkload(object):
         self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtype]
         torch.manual_seed(seed)
         random.seed(seed)
+        M["ops"].single_thread_backward(True)     # as SRRunManager does: no hand-off to the engine's worker thread
         M["dop"].DynamicSeparableConv2d.KERNEL_TRANSFORM_MODE = 1            # train_ofa_net_sr_simple.py:183
         if config == "c3":
             net = M["nets"].OFAMobileNetS4(ks_list=[3, 5, 7], expand_ratio_list=[6], depth_list=[4],
@@ -140,6 +141,7 @@ class TrainWorkload(object):
                 out = self.net(self.lr)
             loss = F.mse_loss(out.float(), self.hr)
         loss.backward()
+        self.M["ops"].flush_deferred()   # the MB blocks' weight gradients: one join of the side stream per backward pass
         if self.reducer is not None:
             self.reducer.reduce()
         self.opt.step()

@@ -220,6 +220,23 @@ int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, void* act_buf, f
 int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, const void* act_buf, const float* stat_buf,
                      const void* dout, void* dx, void* tmp_buf, const ofasr_mbconv_grads* g, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* The MB stack -- all active blocks of OFAMobileNetS4.forward's stage loop (reference ofa_mbs4.py:147-151) in one call per
+ * direction.  items[i] carries block i's descriptor and buffers exactly as ofasr_mbconv_fwd / _bwd take them; block i
+ * reads the output of block i - 1 (the tail of its act_buf), and in the backward block i's dout is items[i + 1].dx
+ * (items[n - 1] takes `dout`, items[0].dx is the gradient of x).  dx buffers are read on the caller's stream only, so
+ * two alternating buffers suffice.  tmp_buf, grads and dx are unused (may be NULL) in the forward. */
+typedef struct {
+    const ofasr_mbconv_desc* desc;
+    void* act_buf;
+    float* stat_buf;
+    void* workspace;
+    size_t workspace_bytes;
+    void* tmp_buf;                      /* backward */
+    const ofasr_mbconv_grads* grads;    /* backward */
+    void* dx;                           /* backward: N*Cin*HW elements */
+} ofasr_mbstack_item;
+int ofasr_mbstack_fwd(const ofasr_mbstack_item* items, int n, const void* x, void* stream);
+int ofasr_mbstack_bwd(const ofasr_mbstack_item* items, int n, const void* x, const void* dout, void* stream);
 /* ofasr_mbconv_bwd runs the weight-gradient kernels on a library-owned side stream beside the input-gradient chain
  * and, by default, ends by ordering them before whatever the caller enqueues next on `stream`.
  * ofasr_mbconv_defer_join(1) (process-wide; returns the previous setting) drops that per-call join: on return dx,

@@ -94,6 +94,8 @@ SIGNATURES = {
     "ofasr_mbconv_stat_floats": (_c_sz, [_c_vp]),
     "ofasr_mbconv_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "ofasr_mbconv_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "ofasr_mbstack_fwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp]),
+    "ofasr_mbstack_bwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp]),
     "ofasr_mbconv_defer_join": (_c_int, [_c_int]),
     "ofasr_mbconv_join": (_c_int, [_c_vp]),
     "ofasr_side_stream": (_c_vp, []),
@@ -161,6 +163,12 @@ class MBConvGrads(ctypes.Structure):
     """mirror of ofasr_mbconv_grads"""
     _fields_ = [("dw1", _c_vp), ("dw2", _c_vp), ("dwdw_max", _c_vp), ("dmats", _c_vp * 3), ("dgamma", _c_vp * 3),
                 ("dbeta", _c_vp * 3)]
+
+
+class MBStackItem(ctypes.Structure):
+    """mirror of ofasr_mbstack_item"""
+    _fields_ = [("desc", _c_vp), ("act_buf", _c_vp), ("stat_buf", _c_vp), ("workspace", _c_vp), ("workspace_bytes", _c_sz),
+                ("tmp_buf", _c_vp), ("grads", _c_vp), ("dx", _c_vp)]
 
 
 class OfasrError(RuntimeError):

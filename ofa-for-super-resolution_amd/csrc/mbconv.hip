@@ -528,7 +528,14 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     const bool wg_bx = fused && bn_fold_enabled() &&
                        dwconv_wgrad_bx_supported(tA, y1, y2, d->N, d->mid, d->H, d->W, d->K, d->dtype);
     BwdXf bx2{y2, s2.mean, s2.scale, s2.shift, coef, coef + d->mid, wg_bx ? nullptr : tC};
-    BwdXf bx1{y1, s1.mean, s1.scale, s1.shift, coef + 2 * d->mid, coef + 3 * d->mid, wg_bx ? tC : tA};
+    // The expand weight gradient forms dy1 from (da1, y1) as well (pw_wgrad_direct_kernel<T, 3>, side stream): the expand
+    // input gradient -- the longest kernel of the chain -- then stores no dy1 (50 MB per block at the north-star shape).
+    // OFASR_MBCONV_WG1_BX=0: the stored dy1 (round 2).
+    static const bool wg1_env = [] { const char* e = getenv("OFASR_MBCONV_WG1_BX"); return !(e && e[0] == '0'); }();
+    const bool wg1_bx = fused && bn_fold && wg1_env &&
+                        pwconv_wgrad_bx_supported(tB, y1, x, d->Cin, d->mid, HW, d->dtype);
+    BwdXf bx1{y1, s1.mean, s1.scale, s1.shift, coef + 2 * d->mid, coef + 3 * d->mid,
+              wg1_bx ? nullptr : (wg_bx ? tC : tA)};
     // The consumers fold the reduction pass's partial slabs themselves (BwdXf::fold_*): no coefficient launch between a
     // reduction and its consumer on the chain (2 x 5.7 us of pure latency per block); the depthwise input gradient also
     // publishes (ka2, kbi2) for the side stream's weight gradient.  OFASR_MBCONV_BN_COEF_FOLD=0: the coefficient kernel.
@@ -613,7 +620,12 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
         if (rc) return rc;
         rc = fork(2);   // dy1 is final
         if (rc) return rc;
-        rc = ofasr_pwconv_wgrad(wg_bx ? tC : tA, x, g->dw1, d->ldw1, d->N, d->Cin, d->mid, HW, d->dtype, side_ws, s.side, sst);
+        if (wg1_bx)   // da1 (tB) and the coefficients the expand input gradient published are final
+            rc = pwconv_wgrad_bx(tB, x, g->dw1, d->ldw1, d->N, d->Cin, d->mid, HW, d->dtype,
+                                 BwdXf{y1, s1.mean, s1.scale, s1.shift, coef + 2 * d->mid, coef + 3 * d->mid, nullptr}, side_ws,
+                                 s.side, sst);
+        else
+            rc = ofasr_pwconv_wgrad(wg_bx ? tC : tA, x, g->dw1, d->ldw1, d->N, d->Cin, d->mid, HW, d->dtype, side_ws, s.side, sst);
         if (rc) return rc;
     } else {
     // BN2 + ReLU6 (in place: da2 -> dy2)
@@ -672,6 +684,51 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
         }
     }
     return rc;
+}
+
+// ---- the MB stack: every active block of the network in ONE host call per direction --------------------------------
+// Block i reads the output of block i - 1 (the last N*Cout*HW elements of its act_buf); in the backward its dout is
+// the dx of block i + 1.  Nothing but a loop over ofasr_mbconv_fwd / _bwd: what it removes is the per-block host path
+// above the C ABI (autograd node, descriptor marshalling, three allocations, the foreign call itself).
+static const void* stack_out_of(const ofasr_mbstack_item& it) {
+    const ofasr_mbconv_desc* d = it.desc;
+    const size_t es = d->dtype == OFASR_F32 ? 4 : 2;
+    const size_t out_elems = (size_t)(d->N * d->Cout * d->H * d->W);
+    return (const char*)it.act_buf + (ofasr_mbconv_act_elems(d) - out_elems) * es;
+}
+
+OFASR_EXPORT int ofasr_mbstack_fwd(const ofasr_mbstack_item* items, int n, const void* x, void* stream) {
+    OFASR_REQUIRE(items && n > 0 && x, OFASR_ERR_INVALID_ARG, "ofasr_mbstack_fwd: null / empty stack");
+    const void* in = x;
+    for (int i = 0; i < n; ++i) {
+        const ofasr_mbstack_item& it = items[i];
+        OFASR_REQUIRE(it.desc != nullptr, OFASR_ERR_INVALID_ARG, "ofasr_mbstack_fwd: block %d has no descriptor", i);
+        if (i > 0) {
+            const ofasr_mbconv_desc *a = items[i - 1].desc, *b = it.desc;
+            OFASR_REQUIRE(a->N == b->N && a->Cout == b->Cin && a->H == b->H && a->W == b->W && a->dtype == b->dtype,
+                          OFASR_ERR_INVALID_ARG, "ofasr_mbstack_fwd: block %d does not take block %d's output", i, i - 1);
+        }
+        const int rc = ofasr_mbconv_fwd(it.desc, in, it.act_buf, it.stat_buf, it.workspace, it.workspace_bytes, stream);
+        if (rc) return rc;
+        in = stack_out_of(it);
+    }
+    return OFASR_OK;
+}
+
+OFASR_EXPORT int ofasr_mbstack_bwd(const ofasr_mbstack_item* items, int n, const void* x, const void* dout, void* stream) {
+    OFASR_REQUIRE(items && n > 0 && x && dout, OFASR_ERR_INVALID_ARG, "ofasr_mbstack_bwd: null / empty stack");
+    const void* g = dout;
+    for (int i = n - 1; i >= 0; --i) {
+        const ofasr_mbstack_item& it = items[i];
+        OFASR_REQUIRE(it.desc && it.dx && it.tmp_buf && it.grads, OFASR_ERR_INVALID_ARG,
+                      "ofasr_mbstack_bwd: block %d lacks a backward buffer", i);
+        const void* in = i > 0 ? stack_out_of(items[i - 1]) : x;
+        const int rc = ofasr_mbconv_bwd(it.desc, in, it.act_buf, it.stat_buf, g, it.dx, it.tmp_buf, it.grads, it.workspace,
+                                        it.workspace_bytes, stream);
+        if (rc) return rc;
+        g = it.dx;
+    }
+    return OFASR_OK;
 }
 
 OFASR_EXPORT int ofasr_debug_mbconv_bn_bwd_stat(int enable) {

@@ -397,6 +397,9 @@ int pwconv_fwd_fold(const void* x, const float* w, int64_t ldw, void* y, int64_t
 // plain forward (no input transform) that leaves the output's statistics partials
 int pwconv_fwd_stat(const void* x, const float* w, int64_t ldw, void* y, int64_t N, int64_t Cin, int64_t Cout,
                     int64_t HW, int dtype, StatOut so, void* stream);
+bool pwconv_wgrad_bx_supported(const void* da, const void* y, const void* x, int64_t Cin, int64_t Cout, int64_t HW, int dtype);
+int pwconv_wgrad_bx(const void* da, const void* x, float* dw, int64_t ldw, int64_t N, int64_t Cin, int64_t Cout, int64_t HW,
+                    int dtype, BwdXf bx, void* workspace, size_t workspace_bytes, void* stream);
 int pwconv_wgrad_xf(const void* dy, const void* x, float* dw, int64_t ldw, int64_t N, int64_t Cin, int64_t Cout,
                     int64_t HW, int dtype, InputXf xf, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -1257,11 +1257,14 @@ struct WdPlan {
     int quads_per_img, total_quads, nsplit, MR, NS;
 };
 
-// XF: 0 none, 1 the R operand, 2 the S operand is read through the fused BN + ReLU6 (InputXf)
+// XF: 0 none, 1 the R operand, 2 the S operand is read through the fused BN + ReLU6 (InputXf); 3: the R operand is the
+// gradient of a BN(+ReLU6) OUTPUT and the product wants the gradient of its INPUT: dy is formed from (R = da, bx.y) with
+// the finished per-channel coefficients bx.ka / bx.kbi as the fragments are read (BwdXf; the expand weight gradient --
+// the chain's expand input gradient then stores no dy1 for this kernel)
 template <typename T, int XF = 0>
 __global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restrict__ R, const T* __restrict__ S,
                                                               float* __restrict__ part, int MR, int NS, int HW,
-                                                              WdPlan wp, InputXf xf = InputXf{}) {
+                                                              WdPlan wp, InputXf xf = InputXf{}, BwdXf bx = BwdXf{}) {
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wr = wave & 3, wc = wave >> 2;
@@ -1300,6 +1303,17 @@ __global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restric
         cmu = xf.mean[colc];
         cbb = fmaf(cmu, csc, xf.shift[colc]);
     }
+    float bka[WD_RB], bkbi[WD_RB];
+    if constexpr (XF == 3) {
+#pragma unroll
+        for (int rb = 0; rb < WD_RB; ++rb) {
+            xsc[rb] = bx.scale[rowc[rb]];
+            xmu[rb] = bx.mean[rowc[rb]];
+            xb[rb] = fmaf(xmu[rb], xsc[rb], bx.shift[rowc[rb]]);
+            bka[rb] = bx.ka[rowc[rb]];
+            bkbi[rb] = bx.kbi[rowc[rb]];
+        }
+    }
     for (int q = q0; q < q1; ++q) {
         const int n = q / wp.quads_per_img;
         const int px = (q - n * wp.quads_per_img) * 64 + 32 * h;   // this lane's first pixel
@@ -1325,6 +1339,16 @@ __global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restric
                 a[rb][j] = *reinterpret_cast<const uint4*>(R + roff + pxc[j]);
             }
         }
+        uint4 ya[XF == 3 ? WD_RB : 1][4];
+        if constexpr (XF == 3) {
+#pragma unroll
+            for (int rb = 0; rb < WD_RB; ++rb) {
+                const long long roff = ((long long)n * MR + rowc[rb]) * HW;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    ya[rb][j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(bx.y) + roff + pxc[j]);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if constexpr (XF == 2) b[j] = xf_apply8_core<T>(b[j], csc, cmu, cbb);
@@ -1335,6 +1359,7 @@ __global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restric
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if constexpr (XF == 1) a[rb][j] = xf_apply8_core<T>(a[rb][j], xsc[rb], xmu[rb], xb[rb]);
+                if constexpr (XF == 3) a[rb][j] = bx_apply8<T>(a[rb][j], ya[rb][j], xmu[rb], xsc[rb], xb[rb], bka[rb], bkbi[rb]);
                 if (!(rs[rb] && okp[j])) a[rb][j] = make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
@@ -1498,9 +1523,10 @@ static int check_pw_args(const char* name, const void* a, const void* b, const v
     return OFASR_OK;
 }
 
-template <typename T, bool XF = false>
+// XF: false plain; true: x is read through InputXf; BXM (with XF false): dy is formed from (dy = da, bx.y) through BwdXf
+template <typename T, bool XF = false, bool BXM = false>
 static int launch_wgrad(const char* name, const void* dy, const void* x, float* dw, int64_t ldw, int64_t N, int64_t Cin,
-                        int64_t Cout, int64_t HW, float* ws, hipStream_t st, InputXf xf = InputXf{}) {
+                        int64_t Cout, int64_t HW, float* ws, hipStream_t st, InputXf xf = InputXf{}, BwdXf bx = BwdXf{}) {
     const WgradPlan p = wgrad_plan(N, Cin, Cout, HW, WgStage<T>::SUB);
     const bool big_is_dy = Cout >= Cin;
     const T* R = (const T*)(big_is_dy ? dy : x);
@@ -1521,6 +1547,13 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
                 else
                     OFASR_LAUNCH((pw_wgrad_direct_kernel<T, 1>), grid, dim3(512), 0, st, R, S, ws, wp.MR, wp.NS,
                                        (int)HW, wp, xf);
+            } else if constexpr (BXM) {
+                if (!big_is_dy) {
+                    set_error("%s: the fused BN backward is implemented for the wide gradient operand (Cout >= Cin)", name);
+                    return OFASR_ERR_UNSUPPORTED;
+                }
+                OFASR_LAUNCH((pw_wgrad_direct_kernel<T, 3>), grid, dim3(512), 0, st, R, S, ws, wp.MR, wp.NS, (int)HW, wp,
+                             InputXf{}, bx);
             } else {
                 OFASR_LAUNCH((pw_wgrad_direct_kernel<T>), grid, dim3(512), 0, st, R, S, ws, wp.MR, wp.NS, (int)HW,
                                    wp);
@@ -1533,7 +1566,7 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
             return check_launch(name);
         }
     }
-    if constexpr (XF) {
+    if constexpr (XF || BXM) {
         set_error("%s: fused input transform needs the aligned 16-bit kernel", name);
         return OFASR_ERR_UNSUPPORTED;
     }
@@ -1717,6 +1750,30 @@ int pwconv_wgrad_xf(const void* dy, const void* x, float* dw, int64_t ldw, int64
     if (dtype == OFASR_F16)
         return launch_wgrad<f16_t, true>(name, dy, x, dw, ldw, N, Cin, Cout, HW, (float*)workspace, st, xf);
     return launch_wgrad<bf16_t, true>(name, dy, x, dw, ldw, N, Cin, Cout, HW, (float*)workspace, st, xf);
+}
+
+bool pwconv_wgrad_bx_supported(const void* da, const void* y, const void* x, int64_t Cin, int64_t Cout, int64_t HW, int dtype) {
+    if (!(dtype == OFASR_F16 || dtype == OFASR_BF16) || Cout < Cin) return false;
+    return aligned_for(da, x, HW, true) && aligned_for(y, x, HW, true);
+}
+
+// dw[:Cout, :Cin] = sum dy * x with dy = BN(+ReLU6) backward of (da, bx.y), finished coefficients in bx.ka / bx.kbi
+int pwconv_wgrad_bx(const void* da, const void* x, float* dw, int64_t ldw, int64_t N, int64_t Cin, int64_t Cout, int64_t HW,
+                    int dtype, BwdXf bx, void* workspace, size_t workspace_bytes, void* stream) {
+    const char* name = "pwconv_wgrad_bx";
+    int rc = check_pw_args(name, da, x, dw, ldw, N, Cin, Cout, HW, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(bx.y && bx.mean && bx.scale && bx.shift && bx.ka && bx.kbi, OFASR_ERR_INVALID_ARG, "%s: null transform", name);
+    OFASR_REQUIRE(pwconv_wgrad_bx_supported(da, bx.y, x, Cin, Cout, HW, dtype), OFASR_ERR_UNSUPPORTED,
+                  "%s: needs 16-bit aligned tensors and Cout >= Cin", name);
+    OFASR_REQUIRE(N * HW > 0, OFASR_ERR_UNSUPPORTED, "%s: empty tensor", name);
+    const size_t need = ofasr_pwconv_wgrad_workspace(N, Cin, Cout, HW);
+    OFASR_REQUIRE(workspace && workspace_bytes >= need, OFASR_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B",
+                  name, workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    if (dtype == OFASR_F16)
+        return launch_wgrad<f16_t, false, true>(name, da, x, dw, ldw, N, Cin, Cout, HW, (float*)workspace, st, InputXf{}, bx);
+    return launch_wgrad<bf16_t, false, true>(name, da, x, dw, ldw, N, Cin, Cout, HW, (float*)workspace, st, InputXf{}, bx);
 }
 
 }  // namespace ofasr

@@ -85,6 +85,11 @@ class FlatGradReducer(object):
         self._touched = [False] * len(self.params)
         self._handles = [p.register_post_accumulate_grad_hook(self._make_hook(i))
                          for i, p in enumerate(self.params)]
+        # gradients the composite MB blocks defer to ops.flush_deferred() do not pass through autograd's AccumulateGrad:
+        # the same bookkeeping through the package's own (public) hook registry
+        from . import ops
+        self._ops = ops
+        self._removers = [ops.register_deferred_grad_hook(p, self._make_hook(i)) for i, p in enumerate(self.params)]
 
     def _make_hook(self, i):
         def hook(_param):
@@ -113,6 +118,7 @@ class FlatGradReducer(object):
     def reduce(self, average=True):
         """one all-reduce over the whole bucket; afterwards parameters that received no gradient in
         this step have .grad None (so Adam skips them, as in the reference)."""
+        self._ops.flush_deferred()    # the deferred weight gradients of the backward pass(es) land in .grad first
         if self.gather:
             self.flat.zero_()
             dst = [v for p, v in zip(self.params, self.views) if p.grad is not None]
@@ -135,4 +141,6 @@ class FlatGradReducer(object):
     def remove(self):
         for h in self._handles:
             h.remove()
-        self._handles = []
+        for r in self._removers:
+            r()
+        self._handles, self._removers = [], []

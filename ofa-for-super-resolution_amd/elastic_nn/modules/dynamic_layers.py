@@ -71,9 +71,7 @@ class DynamicMBConvLayer(MyModule):
         self.depth_conv.conv.active_kernel_size = self.active_kernel_size
         self.point_linear.conv.active_out_channel = self.active_out_channel
         fused = ops.FUSED_BN and self.act_func == "relu6" and not DynamicBatchNorm2d.SET_RUNNING_STATISTICS
-        if (fused and ops.FUSED_BLOCK and self.inverted_bottleneck is not None and x.is_cuda and self.stride == 1
-                and all(m.bn.momentum is not None for m in (self.inverted_bottleneck.bn, self.depth_conv.bn,
-                                                            self.point_linear.bn))):
+        if self.composite_eligible(x):
             return self._forward_composite(x, residual)
         if not fused:
             if self.inverted_bottleneck is not None:
@@ -86,27 +84,40 @@ class DynamicMBConvLayer(MyModule):
         x = ops.bn_act(self.depth_conv.conv(x), self.depth_conv.bn.bn, ops.ACT_RELU6)
         return ops.bn_act(self.point_linear.conv(x), self.point_linear.bn.bn, ops.ACT_NONE, residual)
 
-    def _forward_composite(self, x, residual):
-        """the whole block (+ shortcut when `residual is x`) as one composite HIP call (ops.FusedMBConvFn)."""
+    def composite_eligible(self, x):
+        """the composite HIP call (one per block, ops.FusedMBConvFn, or one per stack, ops.FusedMBStackFn) serves this block"""
+        fused = ops.FUSED_BN and self.act_func == "relu6" and not DynamicBatchNorm2d.SET_RUNNING_STATISTICS
+        return (fused and ops.FUSED_BLOCK and self.inverted_bottleneck is not None and x.is_cuda and self.stride == 1
+                and all(m.bn.momentum is not None for m in (self.inverted_bottleneck.bn, self.depth_conv.bn,
+                                                            self.point_linear.bn)))
+
+    def composite_args(self, in_channels, add_x):
+        """(cfg, params) of the composite call for the ACTIVE sub-network: cfg as ops.FusedMBConvFn / FusedMBStackFn read
+        it, params = (w1, g1, b1, wdw, g2, b2, w2, g3, b3, *transform matrices walked)"""
         dw = self.depth_conv.conv
         K = self.active_kernel_size
         chain = dw._chain(K)
         transform = dw.KERNEL_TRANSFORM_MODE is not None and K < max(dw.kernel_size_list)
         mats = [getattr(dw, "%dto%d_matrix" % (a, b)) for a, b in zip(chain[:-1], chain[1:])] if transform else []
-        add_x = residual is not None and residual is x
         bn1, bn2, bn3 = self.inverted_bottleneck.bn.bn, self.depth_conv.bn.bn, self.point_linear.bn.bn
-        cfg = {"mid": self.active_middle_channel(x.size(1)), "out": self.active_out_channel, "K": K, "chain": chain,
-               "residual": add_x, "bns": (bn1, bn2, bn3)}
+        cfg = {"mid": self.active_middle_channel(in_channels), "out": self.active_out_channel, "K": K, "chain": chain,
+               "residual": add_x, "bns": (bn1, bn2, bn3), "owner": self, "nparams": 9 + len(mats)}
+        params = (self.inverted_bottleneck.conv.conv.weight, bn1.weight, bn1.bias, dw.conv.weight, bn2.weight, bn2.bias,
+                  self.point_linear.conv.conv.weight, bn3.weight, bn3.bias) + tuple(mats)
+        return cfg, params
+
+    def _forward_composite(self, x, residual):
+        """the whole block (+ shortcut when `residual is x`) as one composite HIP call (ops.FusedMBConvFn)."""
+        add_x = residual is not None and residual is x
+        cfg, params = self.composite_args(x.size(1), add_x)
+        bn1, bn2, bn3 = cfg["bns"]
         if ops.FUSED_INFER and not torch.is_grad_enabled() and not (bn1.training or bn2.training or bn3.training) \
                 and (add_x or residual is None):
             # inference with eval-mode BN: the block is one kernel (BN folded, the mid tensor never reaches HBM)
-            y = ops.mbconv_infer(x, cfg, self.inverted_bottleneck.conv.conv.weight, bn1.weight, bn1.bias, dw.conv.weight,
-                                 bn2.weight, bn2.bias, self.point_linear.conv.conv.weight, bn3.weight, bn3.bias, *mats)
+            y = ops.mbconv_infer(x, cfg, *params)
             if y is not None:
                 return y
-        y = ops.FusedMBConvFn.apply(x, cfg, self.inverted_bottleneck.conv.conv.weight, bn1.weight, bn1.bias,
-                                    dw.conv.weight, bn2.weight, bn2.bias, self.point_linear.conv.conv.weight,
-                                    bn3.weight, bn3.bias, *mats)
+        y = ops.FusedMBConvFn.apply(x, cfg, *params)
         if residual is not None and not add_x:
             y = y + residual
         return y

@@ -21,6 +21,9 @@ drives the shuffle stage, d the four MB stages).
 """
 import random
 
+import torch
+
+from ... import ops
 from ...imagenet_codebase.networks.mobilenet_s4 import MobileNetS4
 from ...imagenet_codebase.networks.proxyless_nets import MobileInvertedResidualBlock
 from ...layers import ConvLayer, IdentityLayer
@@ -106,12 +109,36 @@ class OFAMobileNetS4(MobileNetS4):
         seq.append(("head", self.dec_final_output_conv_block))
         return seq
 
+    def _mb_stack(self, x):
+        """the active MB blocks, stage by stage (reference ofa_mbs4.py:147-151).  On the GPU with the composite path on
+        and gradients (or train-mode BN) in play they run as ONE autograd node / foreign call (ops.FusedMBStackFn); the
+        one-kernel inference blocks and every other configuration go block by block."""
+        active = [self.blocks[idx] for stage in range(_N_MB_STAGES)
+                  for idx in self.block_group_info[stage][:self.runtime_depth[stage]]]
+        infer = ops.FUSED_INFER and not torch.is_grad_enabled() and not self.training
+        if (ops.FUSED_STACK and active and x.is_cuda and not infer and all(b.stackable(x) for b in active)):
+            if torch.is_autocast_enabled() and x.dtype == torch.float32:
+                x = x.to(torch.get_autocast_dtype("cuda"))
+            cfgs, params, ch = [], [], x.size(1)
+            for b in active:
+                mb = b.mobile_inverted_conv
+                # what DynamicMBConvLayer.forward sets on its children before it runs them
+                mb.inverted_bottleneck.conv.active_out_channel = mb.active_middle_channel(ch)
+                mb.depth_conv.conv.active_kernel_size = mb.active_kernel_size
+                mb.point_linear.conv.active_out_channel = mb.active_out_channel
+                cfg, ps = mb.composite_args(ch, True)
+                cfgs.append(cfg)
+                params.extend(ps)
+                ch = mb.active_out_channel
+            return ops.mbstack(x, cfgs, params)
+        for b in active:
+            x = b(x)
+        return x
+
     def forward(self, x):
         x = self.dec_first_conv_block(x)
         skip = x
-        for stage in range(_N_MB_STAGES):
-            for idx in self.block_group_info[stage][:self.runtime_depth[stage]]:
-                x = self.blocks[idx](x)
+        x = self._mb_stack(x)
         for i, conv in enumerate(self.dec_final_conv_blocks):
             x = conv(x)
             if i == 0:

@@ -19,6 +19,7 @@ import time
 import torch
 import torch.nn.functional as F
 
+from ... import ops
 from ...imagenet_codebase.run_manager.sr_run_manager import SRRunManager  # noqa: F401
 from ...utils import AverageMeter, device_batch, int2list, list_mean, psnr_y_device, subset_mean
 
@@ -134,6 +135,7 @@ def train_one_epoch(run_manager, args, epoch, warmup_epochs=0, warmup_lr=0):
             sub_losses.append(loss.detach())
             sub_psnrs.append(psnr_y_device(output, images))
             loss.backward()
+            ops.flush_deferred()   # the MB blocks' weight gradients: joined once per backward pass (ops.py)
         run_manager.step()
 
         n = images.size(0)

@@ -21,6 +21,12 @@ class MobileInvertedResidualBlock(MyModule):
             return conv(x, residual=x)      # shortcut add fused into the block's last BN pass
         return conv(x) + skip(x)
 
+    def stackable(self, x):
+        """this block can be one item of ops.FusedMBStackFn: elastic MB layer on the composite path + identity shortcut"""
+        conv, skip = self.mobile_inverted_conv, self.shortcut
+        return (isinstance(skip, IdentityLayer) and not skip._modules and getattr(conv, "accepts_residual", False)
+                and hasattr(conv, "composite_eligible") and conv.composite_eligible(x))
+
     @property
     def module_str(self):
         return "(%s, %s)" % (

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from ... import distributed as dd
+from ... import ops
 from ...graphed import GraphedEval
 from ...utils import AverageMeter, bucket_by_size, device_batch, psnr_y, psnr_y_per_image
 from ..utils import get_net_info
@@ -133,6 +134,7 @@ class SRRunManager(object):
         self.best_acc = 0
         self.start_epoch = 0
         os.makedirs(self.path, exist_ok=True)
+        ops.single_thread_backward(True)   # one process drives one GPU: backward() on the calling thread (ops.py)
 
         if no_gpu or not torch.cuda.is_available():
             raise RuntimeError("SRRunManager drives the MI355X HIP hot path: a GPU is required (no CPU fallback)")
@@ -379,6 +381,7 @@ class SRRunManager(object):
                 loss = args.kd_ratio * torch.nn.functional.mse_loss(output, soft) + loss
             self.zero_grad()
             loss.backward()
+            ops.flush_deferred()   # the MB blocks' weight gradients: joined once per backward pass (ops.py)
             self.step()
             losses.update(loss.item(), images.size(0))
             psnrs.update(psnr_y(output, images), images.size(0))

@@ -498,14 +498,26 @@ FUSED_BLOCK = True   # DynamicMBConvLayer (+ shortcut) through ONE composite FFI
 # Deferred weight gradients of the composite block.  ofasr_mbconv_bwd computes the weight / transform-matrix gradients
 # on the library's side stream; joining that stream at the end of every block's backward makes the next block's
 # input-gradient chain queue behind them (7 % of the north-star step).  In deferred mode the backward node returns dx
-# and the BN gradients only, keeps the call's buffers alive, and a callback at the end of the backward pass
-# (torch's queue_callback, the hook DistributedDataParallel uses) joins the side stream once and then does what
-# AccumulateGrad would have done: p.grad = g or p.grad += g, followed by the parameter's post-accumulate hooks.
-# Visible differences: those .grad fields appear at the end of backward() instead of mid-way (a post-accumulate hook
-# runs once early, as for any parameter whose node receives no gradient, and again after the gradient is in place),
-# tensor hooks registered on the weights do not run, and torch.autograd.grad() does not return them -- use deferred_weight_grads(False) (or
-# OFASR_MBCONV_DEFER_JOIN=0) for such callers.  Only leaf parameters are deferred.
+# and the BN gradients only and keeps the call's buffers alive; flush_deferred() then joins the side stream ONCE and does
+# what AccumulateGrad would have done (p.grad = g, or p.grad += g).
+#
+# Who calls flush_deferred():
+#   * the trainers of this package right after loss.backward() (SRRunManager.train_one_epoch,
+#     progressive_shrinking.train_one_epoch, bench.py), and FlatGradReducer.reduce();
+#   * safety nets, all public torch API: a global optimizer-step pre-hook (so `loss.backward(); optimizer.step()` --
+#     the reference's loop, progressive_shrinking.py:199-203 -- needs no change), the next composite forward, and
+#     Module.zero_grad through the same pre-hook path of the next step.
+#   Code that READS `.grad` between backward() and optimizer.step() (gradient clipping, logging) calls
+#   ops.flush_deferred() first, or runs with deferred_weight_grads(False) / OFASR_MBCONV_DEFER_JOIN=0.
+#   OFASR_DEFER_ENGINE_CALLBACK=1 additionally installs the flush as an end-of-backward callback of the autograd engine
+#   (torch.autograd.Variable._execution_engine.queue_callback, the private hook DistributedDataParallel uses): `.grad` is
+#   then complete when backward() returns.  Off by default because it is not public torch API.
+# Visible differences in deferred mode: those .grad fields appear at the flush instead of mid-way through backward();
+# tensor hooks and torch's post-accumulate-grad hooks registered on the deferred weights do not run for them (use
+# register_deferred_grad_hook below -- FlatGradReducer does); torch.autograd.grad() does not return them.  Only leaf
+# parameters are deferred.
 DEFER_WGRAD = os.environ.get("OFASR_MBCONV_DEFER_JOIN", "1") != "0"
+DEFER_ENGINE_CALLBACK = os.environ.get("OFASR_DEFER_ENGINE_CALLBACK", "0") != "0"
 
 
 class _Deferred(object):
@@ -515,6 +527,8 @@ class _Deferred(object):
     grads = []          # (parameter, gradient) pairs to accumulate after the join
     ext = {}            # device index -> torch view of the library's side stream (None when it is disabled)
     ext_used = set()    # devices whose side stream got work from this module since the last flush
+    hooks = {}          # id(parameter) -> [callables]: run after a deferred gradient has been accumulated
+    opt_hook = None     # handle of the global optimizer-step pre-hook
 
 
 def _lib_side_stream(device):
@@ -539,7 +553,19 @@ def _set_lib_defer(on):
         _Deferred.lib_mode = on
 
 
-def _flush_deferred():
+def register_deferred_grad_hook(param, fn):
+    """fn(param) runs after flush_deferred() has put a deferred gradient into param.grad -- the public stand-in for
+    torch's post-accumulate-grad hooks, which autograd only runs for gradients IT accumulates.  Returns a remover."""
+    lst = _Deferred.hooks.setdefault(id(param), [])
+    lst.append(fn)
+
+    def remove():
+        if fn in lst:
+            lst.remove(fn)
+    return remove
+
+
+def flush_deferred():
     """join the library's side stream into the current stream, then accumulate the held weight gradients."""
     _Deferred.queued = False
     if not (_Deferred.keep or _Deferred.grads):
@@ -562,11 +588,29 @@ def _flush_deferred():
                 acc_src.append(g)
         if acc_dst:                    # one multi-tensor launch instead of one add per parameter
             torch._foreach_add_(acc_dst, acc_src)
-        for p, _ in grads:
-            hooks = getattr(p, "_post_accumulate_grad_hooks", None)
-            if hooks:
-                for h in list(hooks.values()):
+        if _Deferred.hooks:
+            for p, _ in grads:
+                for h in list(_Deferred.hooks.get(id(p), ())):
                     h(p)
+
+
+_flush_deferred = flush_deferred   # (round-2 name)
+
+
+def single_thread_backward(enable=True):
+    """run backward() on the calling thread (torch.autograd.set_multithreading_enabled, public API).  The autograd engine
+    otherwise hands every backward pass to a per-device worker thread; with one process per GPU there is nothing for
+    that thread to overlap with, and the hand-off costs ~1.4 ms of host time per training step here (3.0 against 1.66 ms
+    of backward host time, tools/host_profile.py) -- more than a fifth of the step.  The trainers of this package and
+    bench.py call this once; it is process-wide."""
+    torch.autograd.set_multithreading_enabled(not enable)
+
+
+def _install_flush_nets():
+    """the optimizer-step safety net: any torch optimizer flushes before it reads gradients (public API)"""
+    if _Deferred.opt_hook is None:
+        from torch.optim.optimizer import register_optimizer_step_pre_hook
+        _Deferred.opt_hook = register_optimizer_step_pre_hook(lambda opt, args, kwargs: flush_deferred())
 
 
 # scratch of the composite backward: a fresh tensor per call, or (SHARED_TMP) one cached buffer per size that every
@@ -586,15 +630,16 @@ def _bwd_scratch(numel, dtype, device):
 
 
 def _defer_this_backward(params):
-    """True when this composite backward may leave its weight gradients to the end-of-pass callback."""
+    """True when this composite backward may leave its weight gradients to flush_deferred()."""
     if not DEFER_WGRAD or not all(p.is_leaf for p in params):
         return False
-    if not _Deferred.queued:
+    _install_flush_nets()
+    if DEFER_ENGINE_CALLBACK and not _Deferred.queued:
         try:
-            torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
-        except RuntimeError:      # not inside an engine-driven backward pass
-            return False
-        _Deferred.queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
+            _Deferred.queued = True
+        except (RuntimeError, AttributeError):      # not inside an engine-driven backward pass / API gone
+            pass
     return True
 
 
@@ -787,6 +832,166 @@ class FusedMBConvFn(Function):
             _Deferred.grads.extend((p, gr) for p, gr, wanted in pairs if wanted)
             return (dx, None, None, dg1, db1, None, dg2, db2, None, dg3, db3) + (None,) * len(dmats)
         return (dx, None, dw1, dg1, db1, dwdw, dg2, db2, dw2, dg3, db3) + tuple(dmats)
+
+
+# ------------------------------------------------------------------------------------ MB stack
+# All active MB blocks of the network in ONE autograd node and ONE foreign call per direction (ofasr_mbstack_fwd / _bwd).
+# Per block and direction the per-block path costs ~100 us of host time above the C ABI (module dispatch, autograd node,
+# descriptor marshalling, three allocations) -- 4.6 ms per step against 6.4 ms of GPU time in round 2; here the
+# descriptors are cached per (block, sub-network, shape) and the buffers of all blocks are slices of three allocations.
+FUSED_STACK = os.environ.get("OFASR_MBSTACK", "1") != "0"
+_DESC_CACHE = {}
+_ALIGN = 256
+
+
+def _cached_desc(x_shape, dtype, cfg, w1, g1, b1, wdw, g2, b2, w2, g3, b3, mats):
+    """(descriptor, act elements, stat floats, workspace bytes) of one block call.  Everything in the descriptor is
+    covered by the key: shapes, sub-network, BN modes / momentum / eps, and the addresses the C side dereferences."""
+    bns = cfg["bns"]
+    key = (id(cfg["owner"]), x_shape, dtype, cfg["mid"], cfg["out"], cfg["K"], cfg["residual"], len(mats),
+           w1.data_ptr(), wdw.data_ptr(), w2.data_ptr(), g1.data_ptr(), g2.data_ptr(), g3.data_ptr(),
+           tuple(m.data_ptr() for m in mats),
+           tuple((bn.training, bn.track_running_stats, bn.momentum, bn.eps, bn.running_mean.data_ptr(),
+                  bn.running_var.data_ptr()) for bn in bns))
+    hit = _DESC_CACHE.get(key)
+    if hit is None:
+        class _X(object):   # what _mbconv_desc reads of x
+            pass
+        fake = _X()
+        fake.shape, fake.dtype = x_shape, dtype
+        d = _mbconv_desc(fake, cfg, w1, g1, b1, wdw, g2, b2, w2, g3, b3, mats)
+        L = _C.lib()
+        dp = ctypes.byref(d)
+        hit = (d, int(L.ofasr_mbconv_act_elems(dp)), int(L.ofasr_mbconv_stat_floats(dp)), int(L.ofasr_mbconv_workspace(dp)))
+        if len(_DESC_CACHE) > 4096:
+            _DESC_CACHE.clear()
+        _DESC_CACHE[key] = hit
+    return hit
+
+
+def _round_up(n, a=_ALIGN):
+    return (n + a - 1) // a * a
+
+
+class FusedMBStackFn(Function):
+    """the stage loop of OFAMobileNetS4.forward (reference ofa_mbs4.py:147-151: every active MobileInvertedResidualBlock
+    in turn) as one node.  apply(x, blocks, *params): blocks = [cfg, ...] as DynamicMBConvLayer.composite_args() builds
+    them, each with cfg["nparams"] tensors in params (w1, g1, b1, wdw, g2, b2, w2, g3, b3, *mats)."""
+
+    @staticmethod
+    def forward(ctx, x, blocks, *params):
+        _gpu(x)
+        if _Deferred.grads or _Deferred.keep:   # a backward pass whose gradients were never collected: settle it now
+            flush_deferred()
+        x = x.contiguous()
+        L = _C.lib()
+        N, C, H, W = x.shape
+        es = x.element_size()
+        n = len(blocks)
+        items = (_C.MBStackItem * n)()
+        metas, off, shape = [], 0, (N, C, H, W)
+        act_b = stat_b = ws_b = 0
+        for i, cfg in enumerate(blocks):
+            ps = params[off:off + cfg["nparams"]]
+            off += cfg["nparams"]
+            d, act_n, stat_n, ws_n = _cached_desc(shape, x.dtype, cfg, *ps[:9], ps[9:])
+            metas.append((d, act_b, act_n, stat_b, stat_n, ws_b, ws_n, ps))
+            act_b += _round_up(act_n * es)
+            stat_b += _round_up(stat_n * 4)
+            ws_b += _round_up(ws_n)
+            shape = (N, cfg["out"], H, W)
+        pool = torch.empty(act_b + stat_b + ws_b, dtype=torch.uint8, device=x.device)
+        base = pool.data_ptr()
+        for i, (d, a0, act_n, s0, stat_n, w0, ws_n, ps) in enumerate(metas):
+            it = items[i]
+            it.desc = ctypes.addressof(d)
+            it.act_buf = base + a0
+            it.stat_buf = base + act_b + s0
+            it.workspace = base + act_b + stat_b + w0
+            it.workspace_bytes = ws_n
+        with _timed("mbstack_fwd"):
+            _C.check(L.ofasr_mbstack_fwd(items, n, _p(x), _stream()), "mbstack_fwd")
+        d, a0, act_n = metas[-1][0], metas[-1][1], metas[-1][2]
+        out_n = N * blocks[-1]["out"] * H * W
+        out = pool[a0 + (act_n - out_n) * es:a0 + act_n * es].view(x.dtype).view(N, blocks[-1]["out"], H, W)
+        ctx.save_for_backward(x, pool, *params)
+        ctx.stack = (items, metas, [cfg["bns"] for cfg in blocks], (act_b, stat_b, ws_b))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x, pool, *params = ctx.saved_tensors
+        items, metas, bns, _ = ctx.stack
+        L = _C.lib()
+        N, C, H, W = x.shape
+        es = x.element_size()
+        n = len(metas)
+        dout = dout.contiguous()
+        # per block: tmp scratch, the dense gradient buffers (one fp32 allocation, zeroed by the library block by block),
+        # and dx -- two alternating buffers (dx is only read on this stream) plus the stack's own
+        tmp_b, tmp_off, g_off, g_n = 0, [], [], 0
+        for (d, *_rest) in metas:
+            tmp_off.append(tmp_b)
+            tmp_b += _round_up(N * H * W * (3 * d.mid + d.Cout) * es)
+        tmp = _bwd_scratch(tmp_b, torch.uint8, x.device)
+        sizes_all = []
+        for (d, a0, act_n, s0, stat_n, w0, ws_n, ps) in metas:
+            w1, g1, b1, wdw, g2, b2, w2, g3, b3 = ps[:9]
+            sizes = [w1.numel(), w2.numel(), wdw.numel()] + [g1.numel()] * 2 + [g2.numel()] * 2 + [g3.numel()] * 2 + \
+                [m.numel() for m in ps[9:]]
+            sizes_all.append(sizes)
+            g_off.append(g_n)
+            g_n += sum(sizes)
+        flat = torch.empty(g_n, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        pp = [torch.empty_like(x), torch.empty_like(x)] if n > 1 else []
+        gstructs, grads_out, deferred_pairs = [], [None, None], []
+        all_leaf = all(p.is_leaf for (_, _, _, _, _, _, _, ps) in metas for p in (ps[0], ps[3], ps[6]) + tuple(ps[9:]))
+        defer = all_leaf and _defer_this_backward(())
+        _set_lib_defer(defer)
+        need = ctx.needs_input_grad
+        pi = 2
+        fb = flat.data_ptr()
+        for i, (d, a0, act_n, s0, stat_n, w0, ws_n, ps) in enumerate(metas):
+            sizes = sizes_all[i]
+            parts = flat[g_off[i]:g_off[i] + sum(sizes)].split(sizes)
+            w1, g1, b1, wdw, g2, b2, w2, g3, b3 = ps[:9]
+            mats = ps[9:]
+            dw1, dw2, dwdw = parts[0].view_as(w1), parts[1].view_as(w2), parts[2].view_as(wdw)
+            dmats = [parts[9 + j].view_as(mats[j]) for j in range(len(mats))]
+            g = _C.MBConvGrads()
+            g.dw1, g.dw2, g.dwdw_max = dw1.data_ptr(), dw2.data_ptr(), dwdw.data_ptr()
+            for j, m in enumerate(dmats):
+                g.dmats[j] = m.data_ptr()
+            for j in range(3):
+                g.dgamma[j], g.dbeta[j] = parts[3 + 2 * j].data_ptr(), parts[4 + 2 * j].data_ptr()
+            gstructs.append(g)
+            it = items[i]
+            it.tmp_buf = tmp.data_ptr() + tmp_off[i]
+            it.grads = ctypes.addressof(g)
+            it.dx = dx.data_ptr() if i == 0 else pp[i & 1].data_ptr()
+            # gradients in input order: w1, g1, b1, wdw, g2, b2, w2, g3, b3, *mats
+            wg = [dw1, parts[3], parts[4], dwdw, parts[5], parts[6], dw2, parts[7], parts[8]] + dmats
+            is_w = [True, False, False, True, False, False, True, False, False] + [True] * len(dmats)
+            for j, (gt, isw) in enumerate(zip(wg, is_w)):
+                if defer and isw:
+                    if need[pi + j]:
+                        deferred_pairs.append((ps[j], gt))
+                    grads_out.append(None)
+                else:
+                    grads_out.append(gt)
+            pi += len(ps)
+        with _timed("mbstack_bwd"):
+            _C.check(L.ofasr_mbstack_bwd(items, n, _p(x), _p(dout), _stream()), "mbstack_bwd")
+        if defer:
+            _Deferred.keep.append((x, pool, dout, tmp, flat, pp, dx, bns, items, metas, gstructs, params))
+            _Deferred.grads.extend(deferred_pairs)
+        return tuple([dx] + grads_out[1:])
+
+
+def mbstack(x, blocks, params):
+    return FusedMBStackFn.apply(x, blocks, *params)
 
 
 # ------------------------------------------------------------------------------- dense KxK conv

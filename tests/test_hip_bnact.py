@@ -56,6 +56,7 @@ def test_bn_act_vs_oracle(ora, dtype, training, act, res, shape):
         assert int(bn.num_batches_tracked) == 1
         assert np.array_equal(bn.running_mean.cpu().numpy()[C:], sd["running_mean"][C:])
     y.backward(dy.to(DEV))
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     dyf = dy.float().numpy()
     dz = dyf * ((pre > 0) & (pre < 6)) if act else dyf
     if training:
@@ -99,6 +100,7 @@ def test_bn_bwd_large_shapes(dtype, act, training, shape):
     rm0, rv0 = bn.running_mean.double().cpu().clone(), bn.running_var.double().cpu().clone()
     y = ops.bn_act(xg, bn, act)
     y.backward(dy.to(DEV))
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     xd, dyd = x.double(), dy.double()
     if training:
         mu = xd.mean(dim=(0, 2, 3), keepdim=True)
@@ -147,6 +149,7 @@ def test_bn_golden_reference(golden):
             tag = "c%d_%s" % (C, "train" if training else "eval")
             assert_close(y.detach().cpu().numpy(), g["y_" + tag], 5e-5, 5e-6, "y")
             y.backward(torch.from_numpy(det_uniform(tuple(y.shape), "bn/dy%d" % C)).to(DEV))
+            amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
             assert_close(x.grad.cpu().numpy(), g["dx_" + tag], 1e-4, 1e-5, "dx")
             assert_close(m.bn.weight.grad.cpu().numpy(), g["dgamma_" + tag], 5e-5, 5e-5, "dgamma")
             assert_close(m.bn.bias.grad.cpu().numpy(), g["dbeta_" + tag], 5e-5, 5e-5, "dbeta")
@@ -177,6 +180,7 @@ def test_fused_and_modular_paths_agree():
             y = net(x)
             # NB not mean(y^2): y is a train-mode BN output, whose mean square is constant => zero gradient, pure noise
             (y - target).square().mean().backward()
+            amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
         finally:
             ops.FUSED_BN = True
         outs.append((y.detach().clone(), net.blocks[0].mobile_inverted_conv.depth_conv.conv.conv.weight.grad.clone(),
@@ -207,6 +211,7 @@ def test_composite_block_matches_per_op_path():
             x = x0.to(dtype).clone().requires_grad_(True)
             y = block(x)
             y.backward(dy.to(dtype))
+            amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
         finally:
             ops.FUSED_BLOCK = True
         return (y.detach().float(), x.grad.float(),

@@ -127,6 +127,7 @@ def test_composite_block_16bit_vs_oracle(ora, case, bstat):
         fwd_table = C.launch_table()
         C.reset_launch_counts()
         y.backward(do16.to(DEV))
+        amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
         torch.cuda.synchronize()
         bwd_table = C.launch_table()
         (tmp,) = list(ops._TMP_CACHE.values())
@@ -156,7 +157,9 @@ def test_composite_block_16bit_vs_oracle(ora, case, bstat):
         # backward: BN1 / BN2 have no apply pass -- their consumers read (da, y) through the BN backward (BwdXf variants)
         assert ran(bwd_table, "pw_fanin_pipe_kernel<%s, false, true, true>" % T) == 1, bwd_table   # expand dgrad (+dout)
         assert ran(bwd_table, "pw_wgrad_direct_kernel<%s, 1>" % T) + ran(bwd_table, "pw_wgrad_direct_kernel<%s, 2>" % T) == 1
-        assert ran(bwd_table, "pw_wgrad_direct_kernel<%s, 0>" % T) == 1, bwd_table
+        # the expand weight gradient forms dy1 from (da1, y1) itself (BwdXf, <T, 3>): the expand dgrad stores no dy1
+        assert ran(bwd_table, "pw_wgrad_direct_kernel<%s, 3>" % T) == 1 and \
+            ran(bwd_table, "pw_wgrad_direct_kernel<%s, 0>" % T) == 0, bwd_table
         if Ww in (32, 64) and Hh % 16 == 0 and Hh <= 64:   # depthwise weight gradient on the matrix cores, no reduce launch
             assert ran(bwd_table, "dw_wgrad_mfma_kernel<%s, %d, %d, true, true>" % (T, K, Ww // 32)) == 1, bwd_table
             assert ran(bwd_table, "dw_wgrad_vec") == 0, bwd_table
@@ -291,8 +294,13 @@ def test_composite_block_16bit_vs_oracle(ora, case, bstat):
             near = ora.dwconv_fwd((~safe2).astype(np.float32), np.ones((mid, 1, K, K), np.float32)) > 0
         close16(tB, c16.r16(da1, dtype), dtype, "da1 (depthwise dgrad of the folded BN2 backward)", ~near, 3e-4)
         d1, dg1, db1 = c16.bn_bwd(tB, y1, m1, i1, bnp[0]["weight"], pre1, True, train)
-        dy1_gpu = tC if wg_bx else tA
-        close16(dy1_gpu, c16.r16(d1, dtype), dtype, "dy1 (BN1 backward, stored by the expand dgrad)", safe1, 3e-4)
+        if ran(bwd_table, "pw_wgrad_direct_kernel<%s, 3>" % T):
+            # dy1 is stored nowhere: the expand input gradient (pw_fanin_pipe_kernel<..., BX>) and the expand weight
+            # gradient (pw_wgrad_direct_kernel<T, 3>) both form it from the stored (da1, y1) as they read them
+            dy1_gpu = c16.r16(d1, dtype)
+        else:
+            dy1_gpu = tC if wg_bx else tA
+            close16(dy1_gpu, c16.r16(d1, dtype), dtype, "dy1 (BN1 backward, stored by the expand dgrad)", safe1, 3e-4)
     else:
         d1, dg1, db1 = c16.bn_bwd(c16.r16(da1, dtype), y1, m1, i1, bnp[0]["weight"], pre1, True, train)
         close16(tB, c16.r16(d1, dtype), dtype, "dy1 (depthwise dgrad + BN1 backward)", safe1, 3e-4)
@@ -334,6 +342,7 @@ def test_composite_block_16bit_end_to_end_vs_fp32_oracle(dtype, train):
     xg = x16.to(DEV).requires_grad_(True)
     y = block(xg)
     y.backward(do16.to(DEV))
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     torch.cuda.synchronize()
 
     def rel(a, b):

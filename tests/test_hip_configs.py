@@ -74,6 +74,7 @@ def test_config2_train_step_fp32_and_bf16(nets):
                 y = net(lr.to(DEV))
         loss = F.mse_loss(y.float(), hr.to(DEV))
         loss.backward()
+        amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
         ga = torch.cat([p.grad.detach().double().flatten().cpu() for n, p in net.named_parameters() if p.grad is not None])
         gb = torch.cat([sd[n].grad.double().flatten() for n, p in net.named_parameters() if p.grad is not None])
         for n, p in net.named_parameters():

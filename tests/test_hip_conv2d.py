@@ -52,6 +52,7 @@ def test_conv2d_vs_oracle(ora, case, dtype):
     rt = 1e-2 if dtype == torch.bfloat16 else 2e-3
     assert_close(y.detach().float().cpu().numpy(), y_ref, rt, rt, "y")
     y.backward(torch.from_numpy(dy).to(dtype).to(DEV))
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     dx_ref, dw_ref = ora.conv2d_bwd(dy, x, r16(w))
     scale = float(np.sqrt(Cout * K * K / max(Cin * K * K, 1)))
     assert_close(xt.grad.float().cpu().numpy(), dx_ref, rt, rt * max(1.0, scale), "dx")
@@ -101,6 +102,7 @@ def test_conv2d_full_size_properties(shape):
     dy = (torch.randint(-4, 5, (2, Cout, H, W), generator=g).float() / 4).to(torch.bfloat16).to(DEV)
     y2 = ops.Conv2dFn.apply(xs, w2)
     y2.backward(dy)
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     lhs = float((dy.double() * y2.detach().double()).sum())
     mid = float((xs.grad.double() * xs.detach().double()).sum())
     rhs = float((w2.grad.double() * w2.detach().double()).sum())
@@ -132,6 +134,7 @@ def test_conv2d_ragged_width_vs_oracle(ora, case):
     y_ref = ora.conv2d_fwd(x, r16(w))
     assert_close(y.detach().float().cpu().numpy(), y_ref, 1e-2, 1e-2, "y")
     y.backward(torch.from_numpy(dy).to(dtype).to(DEV))
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     dx_ref, dw_ref = ora.conv2d_bwd(dy, x, r16(w))
     scale = float(np.sqrt(Cout * K * K / max(Cin * K * K, 1)))
     assert_close(xt.grad.float().cpu().numpy(), dx_ref, 1e-2, 1e-2 * max(1.0, scale), "dx")
@@ -163,6 +166,7 @@ def test_conv2d_fp32_vs_oracle(ora, case):
     y_ref = ora.conv2d_fwd(x, w)
     assert_close(y.detach().cpu().numpy(), y_ref, 5e-5, 5e-6, "y")
     y.backward(torch.from_numpy(dy).to(DEV))
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     assert _n_conv(C, True) == 2 and _n_wgrad(C, True) == 1
     dx_ref, dw_ref = ora.conv2d_bwd(dy, x, w)
     scale = float(np.sqrt(Cout * K * K / max(Cin * K * K, 1)))
@@ -268,6 +272,7 @@ def _policy_cases(ora, ops, C):
         C.reset_launch_counts()
         y = ops.conv2d(xt, conv)
         y.backward(torch.from_numpy(dy).to(DEV))
+        amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
         assert C.launch_count("conv_f32_kernel") == want[0] + want[1], (case, C.launch_table())
         assert C.launch_count("conv_f32_wgrad_kernel") == want[2], (case, C.launch_table())
         if min(Cin, Cout) <= 4:
@@ -338,6 +343,7 @@ def test_conv_layer_training_epilogue_statistics_vs_oracle(ora, case, dtype):
     dy = r16(det_uniform(tuple(y.shape), "cvt/dy%s" % (case,)))
     C.reset_launch_counts()
     y.backward(torch.from_numpy(dy).to(dtype).to(DEV))
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     if act == "pixelshuffle":   # the BN backward reads the gradient through the inverse shuffle: no un-shuffle pass
         assert C.launch_count("ps_r2_kernel") == 0 and C.launch_count("ps_generic") == 0, C.launch_table()
         assert C.launch_count("bn_bwd_reduce_ps_kernel") == 1 and C.launch_count("bn_bwd_apply_ps_kernel") == 1
@@ -381,6 +387,7 @@ def test_conv_layer_training_epilogue_statistics_vs_oracle(ora, case, dtype):
         x2 = torch.from_numpy(x).to(dtype).to(DEV).requires_grad_(True)
         y2 = layer(x2)
         y2.backward(torch.from_numpy(dy).to(dtype).to(DEV))
+        amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     finally:
         ops.CONV_BN_EPILOGUE = was
     assert_close(y.detach().float().cpu().numpy(), y2.detach().float().cpu().numpy(), rt, rt, "y vs the un-fused path")

@@ -2,7 +2,7 @@
 ofasr_mbconv_join): the weight-gradient kernels run on the library's side stream and are joined once at the end of the
 backward pass instead of once per block.  Results must be bit-identical to the immediate mode, including gradient
 accumulation over several backward passes (dynamic_batch_size > 1, reference progressive_shrinking.py:152-199),
-post-accumulate hooks (the data-parallel bucket relies on them) and a scratch buffer shared by all blocks."""
+the package's deferred-gradient hooks (the data-parallel bucket relies on them) and a scratch buffer shared by all blocks."""
 import random
 
 import pytest
@@ -32,6 +32,7 @@ def _two_pass_grads(net, lr, hr, hooks=None):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             out = net(lr)
         F.mse_loss(out.float(), hr).backward()
+        amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     torch.cuda.synchronize()
     return {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in net.named_parameters()}
 
@@ -64,29 +65,52 @@ def test_deferred_equals_immediate_with_accumulation(shared_tmp):
     assert n_def > 50
 
 
-def test_deferred_runs_post_accumulate_hooks():
+def test_deferred_grad_hooks_and_safety_nets():
+    """gradients that flush_deferred() accumulates run the hooks of ops.register_deferred_grad_hook (the public stand-in
+    for torch's post-accumulate hooks, which FlatGradReducer uses); without an explicit flush the optimizer-step pre-hook
+    and the next composite forward settle a pending backward pass (all public torch API; the engine callback is opt-in)."""
     ops = amd("ops")
+    assert not ops.DEFER_ENGINE_CALLBACK, "the default mode must not depend on torch's private engine callback"
     net = _net()
     seen = []
     w = net.blocks[0].mobile_inverted_conv.point_linear.conv.conv.weight
     dw = net.blocks[0].mobile_inverted_conv.depth_conv.conv.conv.weight
-    hs = [w.register_post_accumulate_grad_hook(lambda p: seen.append(("pl", p.grad is not None))),
-          dw.register_post_accumulate_grad_hook(lambda p: seen.append(("dw", p.grad is not None)))]
+    rm = [ops.register_deferred_grad_hook(w, lambda p: seen.append(("pl", p.grad is not None))),
+          ops.register_deferred_grad_hook(dw, lambda p: seen.append(("dw", p.grad is not None)))]
     was = ops.deferred_weight_grads(True)
     try:
         random.seed(3)
         net.sample_active_subnet()
+        x = torch.rand(2, 3, 32, 32, device=DEV)
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            out = net(torch.rand(2, 3, 32, 32, device=DEV))
+            out = net(x)
         out.float().square().mean().backward()
+        assert w.grad is None and ops._Deferred.grads, "deferred mode: the weight gradients are pending after backward()"
+        ops.flush_deferred()
+        assert sorted(seen) == [("dw", True), ("pl", True)] and w.grad is not None and dw.grad is not None
+        ref = w.grad.clone()
+        # (1) the optimizer-step pre-hook
+        net.zero_grad(set_to_none=True)
+        opt = torch.optim.SGD([w], lr=0.0)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = net(x)
+        out.float().square().mean().backward()
+        assert w.grad is None
+        opt.step()
+        assert w.grad is not None and torch.equal(w.grad, ref) and not ops._Deferred.grads
+        # (2) the next composite forward
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = net(x)
+        out.float().square().mean().backward()
+        assert w.grad is None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            net(x)
+        assert w.grad is not None and torch.equal(w.grad, ref)
     finally:
         ops.deferred_weight_grads(was)
-        for h in hs:
-            h.remove()
-    # the engine also runs a parameter's hooks when its node receives no gradient (p.grad still None there); the flush
-    # runs them again once the gradient is in place
-    assert sorted(seen[-2:]) == [("dw", True), ("pl", True)]
-    assert w.grad is not None and dw.grad is not None
+        for r in rm:
+            r()
 
 
 def test_autograd_grad_falls_back_outside_accumulate_callers():

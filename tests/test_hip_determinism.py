@@ -29,6 +29,7 @@ for step in range(3):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         out = net(lr)
     loss = F.mse_loss(out.float(), hr); loss.backward()
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     h.update(out.detach().float().cpu().numpy().tobytes())
     for n, p in net.named_parameters():
         if p.grad is not None:

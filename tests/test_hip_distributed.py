@@ -58,6 +58,7 @@ def _worker(rank, world, init_file, out_dir):
                 with torch.autocast("cuda", dtype=torch.bfloat16):
                     out = net(lr[shard])
                 F.mse_loss(out.float(), hr[shard]).backward()
+                ops.flush_deferred()          # deferred weight gradients -> .grad (ops.py)
 
         # single-process shard gradients (what each rank would compute alone), from the same starting state
         ref = []

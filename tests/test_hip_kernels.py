@@ -87,6 +87,7 @@ def test_pixel_shuffle_backward_is_unshuffle(ops):
     y = ops.pixel_shuffle(x, 2)
     dy = G(det_uniform(tuple(y.shape), "gps/bw/dy"))
     y.backward(dy)
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     assert torch.equal(x.grad, torch.nn.functional.pixel_unshuffle(dy, 2))
 
 
@@ -123,6 +124,7 @@ def test_ktransform_golden(ops, golden, mode, C, k):
     from oracle import oracle
     _, df = oracle.dwconv_bwd(dy, x, g["filter_" + tag])
     f.backward(G(df))
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     assert_close(H(w7.grad), g["dw7_" + tag], 2e-5, 2e-5, "dw7")
     if mats:
         assert_close(H(m75.grad), g["dm75_" + tag], 2e-5, 2e-5, "dm75")
@@ -149,6 +151,7 @@ def test_ktransform_full_width(ops, ora):
             f = ops.KTransformFn.apply(wt, C, (7, 5) if k == 5 else (7, 5, 3), True, *([a] if k == 5 else [a, b]))
             assert_close(H(f), f_ref, 2e-5, 2e-6, "f")
             f.backward(G(df))
+            amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
             assert_close(H(wt.grad), dw_ref, 2e-5, 2e-5, "dw")
             assert_close(H(a.grad), dm_ref["7to5"], 5e-5, 1e-4, "dm75")
             if k == 3:
@@ -186,6 +189,7 @@ def test_dwconv_vs_oracle(ops, ora, shape, k, dtype):
     y_ref = ora.dwconv_fwd(x, f)
     assert_close(H(y), y_ref, what="y", **tol(dtype, k))
     y.backward(G(dy, dtype))
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     dx_ref, df_ref = ora.dwconv_bwd(dy, x, f)
     assert_close(H(xt.grad), dx_ref, what="dx", **tol(dtype, k))
     # df sums N*H*W products of exactly-representable inputs in fp32: fp32 tolerance for all dtypes
@@ -203,6 +207,7 @@ def test_dwconv_golden(ops, golden, mode, C, k):
     y = ops.dwconv(x, G(g["filter_" + tag]))
     assert_close(H(y), g["y_" + tag], 2e-5, 2e-6 * k, "y")
     y.backward(G(det_uniform(tuple(y.shape), "dw/dy/" + tag)))
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     assert_close(H(x.grad), g["dx_" + tag], 2e-5, 2e-6 * k, "dx")
 
 
@@ -244,6 +249,7 @@ def test_dwconv_full_size_16bit_matrix_core_path(ops):
     assert float(y[:, :, :2].abs().max()) == 0 and float(y[:, :, :, 62:].abs().max()) == 0
     g = torch.randn_like(y)
     y.backward(g)                # dx[h, w] = g[h + 2, w - 2]
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     assert torch.equal(xr.grad[:, :, :62, 2:], g[:, :, 2:, :62])
     assert float(xr.grad[:, :, 62:].abs().max()) == 0 and float(xr.grad[:, :, :, :2].abs().max()) == 0
 
@@ -283,6 +289,7 @@ def test_pwconv_vs_oracle(ops, ora, case, dtype):
     y_ref = ora.pwconv_fwd(x, w_eff, Cout)
     assert_close(H(y), y_ref, what="y", **tol(dtype))
     y.backward(G(dy, dtype))
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     dx_ref, _ = ora.pwconv_bwd(dy, x, w_eff)
     _, dw_ref = ora.pwconv_bwd(dy, x, w)
     assert_close(H(xt.grad), dx_ref, what="dx", **tol(dtype, np.sqrt(Cout / Cin) if Cout > Cin else 1.0))
@@ -300,6 +307,7 @@ def test_pwconv_golden_expand(ops, golden, oc):
     y = ops.pwconv(x, w, oc)
     assert_close(H(y), g["expand_y_%d" % oc], 2e-5, 2e-6, "y")
     y.backward(G(det_uniform(tuple(y.shape), "pw/expand/dy%d" % oc)))
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     assert_close(H(x.grad), g["expand_dx_%d" % oc], 2e-5, 2e-6, "dx")
     assert_close(H(w.grad), g["expand_dw_%d" % oc], 2e-5, 2e-5, "dw")
 
@@ -312,6 +320,7 @@ def test_pwconv_golden_project(ops, golden, ic):
     y = ops.pwconv(x, w, 64)
     assert_close(H(y), g["project_y_%d" % ic], 2e-5, 2e-6, "y")
     y.backward(G(det_uniform(tuple(y.shape), "pw/project/dy%d" % ic)))
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     assert_close(H(x.grad), g["project_dx_%d" % ic], 2e-5, 2e-6, "dx")
     assert_close(H(w.grad), g["project_dw_%d" % ic], 2e-5, 2e-5, "dw")
 

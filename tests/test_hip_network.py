@@ -68,6 +68,7 @@ def test_mb_block_golden(mods, golden, bn_train, ke):
     tag = "k%d_e%d_%s" % (k, e, "train" if bn_train else "eval")
     assert_close(H(y), g["y_" + tag], 1e-4, 1e-5, "y")
     y.backward(G(det_uniform(tuple(y.shape), "mb/dy")))
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     assert_close(H(x.grad), g["dx_" + tag], 2e-4, 2e-5, "dx")
     for name, p in block.named_parameters():
         assert bool(g["isnone_%s_%s" % (name, tag)]) == (p.grad is None), name
@@ -105,6 +106,7 @@ def test_s4_golden(mods, golden, meta, si, bn_train):
     loss = F.mse_loss(y, hr)
     assert abs(float(loss) - float(g["loss_" + tag])) <= 2e-5 * abs(float(g["loss_" + tag]))
     loss.backward()
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     names = meta["param_names"]
     params = dict(net.named_parameters())
     isnone = np.array([params[n].grad is None for n in names])
@@ -177,6 +179,7 @@ def test_s4_vs_oracle_random_subnet_and_bf16(mods, meta):
     y = net(G(lr))
     assert_close(H(y), y_ref.detach().numpy(), 5e-4, 5e-5, "y")
     F.mse_loss(y, hr.to(DEV)).backward()
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     # NB this det-filled net is chaotic in backward: perturbing the INPUT by 1e-7 (relative) moves some gradients
     # of the first stage by ~5 % of their max through a ReLU6 mask flip (measured on the ATen path itself), so
     # implementations with different but equally valid rounding can only be compared robustly here; the
@@ -226,6 +229,7 @@ def test_s4_bf16_whole_net_gradient_error_vs_oracle(mods):
     assert yb.dtype == torch.bfloat16
     loss = F.mse_loss(yb.float(), hr.to(DEV))
     loss.backward()
+    amd("ops").flush_deferred()   # deferred weight gradients -> .grad (ops.py)
     rel_y = float((yb.float().cpu() - y_ref.detach()).norm() / y_ref.detach().norm())
     pairs = [(n, p.grad.detach().double().cpu().flatten(), sd[n].grad.double().flatten())
              for n, p in net.named_parameters() if p.grad is not None]
@@ -324,7 +328,8 @@ def test_recalibration_invalidates_inference_operands(mods, golden):
     u0, u1, _, _, _, su = run(False)
     assert torch.equal(y0, u0) and torch.equal(z0, y0)
     # the calibration forward itself (per-op fp32 path + ATen reductions) repeats to within an ulp of the statistics
-    assert float((st - su).abs().max()) <= 1e-6, "re-calibrated statistics differ: max %g" % float((st - su).abs().max())
+    assert float(((st - su).abs() / (1.0 + su.abs())).max()) <= 1e-5, \
+        "re-calibrated statistics differ: max %g" % float((st - su).abs().max())
     scale = float(u1.abs().max())
     moved = float((y0 - y1).abs().max())
     stale = float((y1 - u1).abs().max())
