@@ -27,6 +27,11 @@ typedef __attribute__((ext_vector_type(16))) float cf_f32x16;
 constexpr int CF_TH = 4, CF_TW = 32, CF_KC = 16, CF_MB = 64;
 constexpr int CF_WG_RB = 1;    // weight gradient: 32-row output-channel blocks per wave
 constexpr int CF_WG_TH = 4;    // weight gradient: rows of the pixel tile staged per barrier round
+// weight gradient: waves per kernel row.  A block of K = 5 waves puts two of them on one SIMD and one on each of the
+// others, so the matrix pipes of three SIMDs idle half the time (5/8 of the fp32 matrix rate at best, whatever the
+// number of blocks per CU -- every block maps its waves the same way).  With two waves per kernel row, each on half of
+// the tile's pixel pairs, a block is 10 waves = 3 + 3 + 2 + 2 (10/12); the two halves write separate partial slabs.
+constexpr int CF_WG_HALVES = 2;
 
 // weight image [kc][ty][tx][kk = 16][m = Mpad] fp32 (zeros beyond the slice)
 __global__ void __launch_bounds__(256) conv_f32_prep_kernel(const float* __restrict__ w, float* __restrict__ wimg, int Cin,
@@ -118,10 +123,10 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(const float* __restrict__
 
 // ---- weight gradient: partial[split][co][ci][ty][tx] over the block's pixel tiles
 template <int KS>
-__global__ void __launch_bounds__(64 * KS) conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ void __launch_bounds__(64 * KS * CF_WG_HALVES) conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                  float* __restrict__ part, int Cin, int Cout, int H, int W,
                                                                  int tiles_x, int tiles_y, int ntiles, int nsplit) {
-    constexpr int P = KS / 2, THREADS = 64 * KS;
+    constexpr int P = KS / 2, THREADS = 64 * KS * CF_WG_HALVES;
     constexpr int RH = CF_WG_TH + KS - 1, RW = CF_TW + KS - 1;
     constexpr int GPL = CF_WG_TH * CF_TW + 1;                  // dY plane pitch: bank = (co + pixel) % 32 -> conflict-free A reads
     constexpr int XPL = RH * RW + 1;
@@ -132,7 +137,8 @@ __global__ void __launch_bounds__(64 * KS) conv_f32_wgrad_kernel(const float* __
     __shared__ float Gs[NCO * GPL];
     __shared__ float Xs[32 * XPL];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's kernel row
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty = wv % KS, half = wv / KS;                    // this wave's kernel row and its share of the pixel pairs
     const int c = lane & 31, kk = lane >> 5;
     // Block order: the (co, ci) groups of one pixel split read the same dY / X tiles, so they should run at the same time
     // on the same XCD (each XCD has its own L2; consecutive workgroup ids go round the 8 XCDs).  id = 8 * (G * q + group)
@@ -154,8 +160,9 @@ __global__ void __launch_bounds__(64 * KS) conv_f32_wgrad_kernel(const float* __
     const int t0 = (int)((long long)split * ntiles / nsplit), t1 = (int)((long long)(split + 1) * ntiles / nsplit);
     auto compute = [&]() {
         // pixel pair s = (row r, columns 2q, 2q+1); lane (c, kk): A = dY[co = c][pixel 2s + kk], B = X[ci = c][same pixel + tap]
+        constexpr int NS = CF_WG_TH * CF_TW / 2 / CF_WG_HALVES;
 #pragma unroll 2
-        for (int s = 0; s < CF_WG_TH * CF_TW / 2; ++s) {
+        for (int s = half * NS; s < (half + 1) * NS; ++s) {
             const int p = 2 * s + kk, r = p / CF_TW, col = p % CF_TW;
             float a[NRB];
 #pragma unroll
@@ -259,7 +266,7 @@ __global__ void __launch_bounds__(64 * KS) conv_f32_wgrad_kernel(const float* __
     }
     }
     // D[row = co][col = ci]
-    float* dst = part + (long long)split * Cout * Cin * KS * KS;
+    float* dst = part + ((long long)split * CF_WG_HALVES + half) * Cout * Cin * KS * KS;
     const int ci = ci0 + c;
     if (ci < Cin) {
 #pragma unroll
@@ -274,13 +281,33 @@ __global__ void __launch_bounds__(64 * KS) conv_f32_wgrad_kernel(const float* __
     }
 }
 
+// 16 outputs x 16 slab lanes per block: lane z adds the slabs z, z + 16, ... in that order (8 requests in flight), the 16
+// lanes are then added in lane order: a fixed order, so the result is deterministic
 __global__ void __launch_bounds__(256) conv_f32_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                    long long total, int nsplit) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
+                                                                    long long total, int nslabs) {
+    __shared__ float red[256];
+    const int el = threadIdx.x & 15, zl = threadIdx.x >> 4;
+    const long long idx = (long long)blockIdx.x * 16 + el;
+    const long long idc = idx < total ? idx : total - 1;
     float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += part[(long long)z * total + idx];
-    dw[idx] = s;
+    for (int z0 = zl; z0 < nslabs; z0 += 16 * 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int z = z0 + 16 * j < nslabs ? z0 + 16 * j : nslabs - 1;
+            v[j] = part[(long long)z * total + idc];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += z0 + 16 * j < nslabs ? v[j] : 0.f;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (zl == 0 && idx < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[16 * j + el];
+        dw[idx] = t;
+    }
 }
 
 static int cf_mpad(int64_t M) { return (int)(cdiv(M, CF_MB) * CF_MB); }
@@ -353,7 +380,7 @@ OFASR_EXPORT int ofasr_conv2d_f32_dgrad(const void* dy, const float* w, void* dx
 
 OFASR_EXPORT size_t ofasr_conv2d_f32_wgrad_workspace(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int K) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || !(K == 3 || K == 5)) return 0;
-    size_t need = (size_t)cf_nsplit(N, Cin, Cout, H, W) * Cout * Cin * K * K * sizeof(float);
+    size_t need = (size_t)cf_nsplit(N, Cin, Cout, H, W) * CF_WG_HALVES * Cout * Cin * K * K * sizeof(float);
     const int64_t Ct = Cin < Cout ? Cin : Cout, Cw = Cin < Cout ? Cout : Cin;
     if (conv_thin_wgrad_supported(Ct, Cw, K, H, W, OFASR_F32, nullptr, nullptr)) {   // the head / stem: csrc/conv_thin.hip
         const size_t thin = conv_thin_wgrad_workspace(N, Ct, Cw, H, W, K, OFASR_F32);
@@ -387,15 +414,15 @@ OFASR_EXPORT int ofasr_conv2d_f32_wgrad(const void* dy, const void* x, float* dw
     prof_note(4.0 * (double)N * (double)H * (double)W * (double)(Cin + Cout),
               2.0 * (double)N * (double)H * (double)W * (double)Cin * (double)Cout * K * K);
     if (K == 5)
-        OFASR_LAUNCH(conv_f32_wgrad_kernel<5>, grid, dim3(64 * 5), 0, st, (const float*)dy, (const float*)x, (float*)workspace,
+        OFASR_LAUNCH(conv_f32_wgrad_kernel<5>, grid, dim3(64 * 5 * CF_WG_HALVES), 0, st, (const float*)dy, (const float*)x, (float*)workspace,
                      (int)Cin, (int)Cout, (int)H, (int)W, tiles_x, tiles_y, ntiles, nsplit);
     else
-        OFASR_LAUNCH(conv_f32_wgrad_kernel<3>, grid, dim3(64 * 3), 0, st, (const float*)dy, (const float*)x, (float*)workspace,
+        OFASR_LAUNCH(conv_f32_wgrad_kernel<3>, grid, dim3(64 * 3 * CF_WG_HALVES), 0, st, (const float*)dy, (const float*)x, (float*)workspace,
                      (int)Cin, (int)Cout, (int)H, (int)W, tiles_x, tiles_y, ntiles, nsplit);
     int rc = check_launch(name);
     if (rc) return rc;
     const long long total = (long long)Cout * Cin * K * K;
-    OFASR_LAUNCH(conv_f32_wgrad_reduce_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
-                 total, nsplit);
+    OFASR_LAUNCH(conv_f32_wgrad_reduce_kernel, dim3((unsigned)cdiv(total, 16)), dim3(256), 0, st, (const float*)workspace, dw,
+                 total, nsplit * CF_WG_HALVES);
     return check_launch(name);
 }

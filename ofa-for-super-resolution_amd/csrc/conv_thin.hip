@@ -952,8 +952,8 @@ static CtWgGeom ct_wg_geom(int64_t N, int64_t Ct, int64_t Cw, int64_t H, int64_t
 
 bool conv_thin_wgrad_supported(int64_t Ct, int64_t Cw, int K, int64_t H, int64_t W, int dtype, const void* a, const void* b) {
     if (!conv_thin_enabled() || !(K == 3 || K == 5) || Ct * K > 16 || Ct > 4 || !(Cw == 32 || Cw == 64)) return false;
-    const int es = dtype == OFASR_F32 ? 4 : 2;
-    if (W % (16 / es) != 0 || W > 1024) return false;
+    // a lane's wide fragment is 8 consecutive pixels of a row in either dtype: they must be all inside or all outside it
+    if (W % 8 != 0 || W > 1024) return false;
     return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
 }
 

@@ -528,10 +528,13 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     const bool wg_bx = fused && bn_fold_enabled() &&
                        dwconv_wgrad_bx_supported(tA, y1, y2, d->N, d->mid, d->H, d->W, d->K, d->dtype);
     BwdXf bx2{y2, s2.mean, s2.scale, s2.shift, coef, coef + d->mid, wg_bx ? nullptr : tC};
-    // The expand weight gradient forms dy1 from (da1, y1) as well (pw_wgrad_direct_kernel<T, 3>, side stream): the expand
-    // input gradient -- the longest kernel of the chain -- then stores no dy1 (50 MB per block at the north-star shape).
-    // OFASR_MBCONV_WG1_BX=0: the stored dy1 (round 2).
-    static const bool wg1_env = [] { const char* e = getenv("OFASR_MBCONV_WG1_BX"); return !(e && e[0] == '0'); }();
+    // Optionally the expand weight gradient forms dy1 from (da1, y1) as well (pw_wgrad_direct_kernel<T, 3>, side stream), and
+    // the expand input gradient -- the longest kernel of the chain -- stores no dy1 (50 MB per block at the north-star
+    // shape).  OFF by default (OFASR_MBCONV_WG1_BX=1 enables it): the chain's kernel gets 11 us shorter (54 -> 43 us) but
+    // the weight-gradient kernel 39 us longer (28 -> 67 us: ten vector instructions per element on twelve fragments per
+    // quad make it issue-bound), and with the host out of the way (round 3) the step is bound by the GPU's total work:
+    // 2445 against 2514 images/s, two A/B pairs on one box.  (While the step was host-bound the same switch gained 1.2 %.)
+    static const bool wg1_env = [] { const char* e = getenv("OFASR_MBCONV_WG1_BX"); return e && e[0] == '1'; }();
     const bool wg1_bx = fused && bn_fold && wg1_env &&
                         pwconv_wgrad_bx_supported(tB, y1, x, d->Cin, d->mid, HW, d->dtype);
     BwdXf bx1{y1, s1.mean, s1.scale, s1.shift, coef + 2 * d->mid, coef + 3 * d->mid,

@@ -32,6 +32,8 @@ CASES = [
     (2, 16, 40, 9, 24, 3),
     (3, 64, 160, 6, 64, 3),     # wgrad: two 128-row slabs
     (2, 96, 24, 4, 16, 5),      # wgrad: two input-channel slabs, thin output
+    (2, 64, 3, 6, 24, 3),       # 3x3 head (X4 nets): csrc/conv_thin.hip with k = 3
+    (2, 3, 64, 5, 40, 3),       # 3x3 stem
 ]
 
 
@@ -141,7 +143,8 @@ def test_conv2d_ragged_width_vs_oracle(ora, case):
     assert_close(conv.weight.grad.cpu().numpy(), dw_ref, 1e-3, 1e-3 * float(np.abs(dw_ref).max()), "dw")
 
 
-@pytest.mark.parametrize("case", CASES + [(1, 64, 64, 9, 125, 5), (2, 3, 64, 7, 62, 5), (1, 16, 16, 5, 13, 3),
+@pytest.mark.parametrize("case", CASES + [(1, 64, 3, 6, 4, 3),     # X4 encoder tail at 6 x 4: narrower than a wide fragment of the thin weight gradient
+                                          (1, 64, 64, 9, 125, 5), (2, 3, 64, 7, 62, 5), (1, 16, 16, 5, 13, 3),
                                           (2, 64, 256, 16, 16, 5), (1, 40, 70, 6, 33, 3)])
 def test_conv2d_fp32_vs_oracle(ora, case):
     """fp32 activations (the reference's arithmetic) on the fp32 matrix instruction (csrc/conv2d_f32.hip): forward,
