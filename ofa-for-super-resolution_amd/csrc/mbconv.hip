@@ -372,9 +372,10 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
                       stream);
 }
 
-OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, const void* act_buf, const float* stat_buf,
-                                  const void* dout, void* dx, void* tmp_buf, const ofasr_mbconv_grads* g,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+// prezeroed: the caller has cleared the nine gradient buffers on `stream` already (ofasr_mbstack_bwd: one fill for all blocks)
+static int mbconv_bwd_impl(const ofasr_mbconv_desc* d, const void* x, const void* act_buf, const float* stat_buf,
+                           const void* dout, void* dx, void* tmp_buf, const ofasr_mbconv_grads* g, void* workspace,
+                           size_t workspace_bytes, void* stream, bool prezeroed) {
     const char* name = "ofasr_mbconv_bwd";
     int rc = check_desc(name, d);
     if (rc) return rc;
@@ -466,7 +467,9 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     const bool split_fill = ss.enabled;
     const bool bn_sliced = d->mid < d->Cmid_max || d->Cout < d->Cout_max;
     hipError_t e = hipSuccess;
-    if (!split_fill) {
+    if (prezeroed) {
+        // nothing to clear
+    } else if (!split_fill) {
         if ((size_t)(hi - lo) == sum) {   // disjoint spans (validated above) tiling [lo, hi) exactly
             e = hipMemsetAsync(lo, 0, sum, st);
         } else {
@@ -502,7 +505,7 @@ OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, con
     // project 1x1: weight gradient (side) beside input gradient + BN2 backward (main)
     rc = fork(0);   // dy3 (t3) is final
     if (rc) return rc;
-    if (split_fill) {
+    if (split_fill && !prezeroed) {
         const hipError_t ef = fill(0, 3, (hipStream_t)sst);
         OFASR_REQUIRE(ef == hipSuccess, OFASR_ERR_LAUNCH, "%s: memset failed: %s", name, hipGetErrorString(ef));
     }
@@ -720,18 +723,58 @@ OFASR_EXPORT int ofasr_mbstack_fwd(const ofasr_mbstack_item* items, int n, const
 
 OFASR_EXPORT int ofasr_mbstack_bwd(const ofasr_mbstack_item* items, int n, const void* x, const void* dout, void* stream) {
     OFASR_REQUIRE(items && n > 0 && x && dout, OFASR_ERR_INVALID_ARG, "ofasr_mbstack_bwd: null / empty stack");
+    // The dense parameter gradients of ALL blocks: when the caller handed them out as slices of one allocation (the host
+    // mirror does) they are cleared with ONE fill on the caller's stream, ahead of every kernel of either stream (the side
+    // stream's kernels wait for fork events recorded later on this stream) -- instead of two fills per block.
+    bool prezeroed = false;
+    {
+        const char *lo = nullptr, *hi = nullptr;
+        size_t sum = 0;
+        bool ok = true;
+        for (int i = 0; i < n && ok; ++i) {
+            const ofasr_mbconv_desc* d = items[i].desc;
+            const ofasr_mbconv_grads* g = items[i].grads;
+            if (!d || !g || !g->dw1 || !g->dw2 || !g->dwdw_max) { ok = false; break; }
+            const int kmax = d->ks[0];
+            const struct { const void* p; size_t nbytes; } sp[9] = {
+                {g->dw1, (size_t)d->Cmid_max * d->ldw1 * sizeof(float)}, {g->dw2, (size_t)d->Cout_max * d->ldw2 * sizeof(float)},
+                {g->dwdw_max, (size_t)d->Cmid_max * kmax * kmax * sizeof(float)},
+                {g->dgamma[0], (size_t)d->Cmid_max * sizeof(float)}, {g->dbeta[0], (size_t)d->Cmid_max * sizeof(float)},
+                {g->dgamma[1], (size_t)d->Cmid_max * sizeof(float)}, {g->dbeta[1], (size_t)d->Cmid_max * sizeof(float)},
+                {g->dgamma[2], (size_t)d->Cout_max * sizeof(float)}, {g->dbeta[2], (size_t)d->Cout_max * sizeof(float)}};
+            for (const auto& q : sp) {
+                if (!q.p) { ok = false; break; }
+                const char* p = (const char*)q.p;
+                lo = (!lo || p < lo) ? p : lo;
+                hi = (!hi || p + q.nbytes > hi) ? p + q.nbytes : hi;
+                sum += q.nbytes;
+            }
+        }
+        // one fill when the span is at most the transform-matrix gradients (which the kernels write in full) larger
+        if (ok && lo && (size_t)(hi - lo) >= sum && (size_t)(hi - lo) <= sum + (size_t)n * 3 * 1024 * sizeof(float)) {
+            const hipError_t e = hipMemsetAsync(const_cast<char*>(lo), 0, (size_t)(hi - lo), as_stream(stream));
+            OFASR_REQUIRE(e == hipSuccess, OFASR_ERR_LAUNCH, "ofasr_mbstack_bwd: memset failed: %s", hipGetErrorString(e));
+            prezeroed = true;
+        }
+    }
     const void* g = dout;
     for (int i = n - 1; i >= 0; --i) {
         const ofasr_mbstack_item& it = items[i];
         OFASR_REQUIRE(it.desc && it.dx && it.tmp_buf && it.grads, OFASR_ERR_INVALID_ARG,
                       "ofasr_mbstack_bwd: block %d lacks a backward buffer", i);
         const void* in = i > 0 ? stack_out_of(items[i - 1]) : x;
-        const int rc = ofasr_mbconv_bwd(it.desc, in, it.act_buf, it.stat_buf, g, it.dx, it.tmp_buf, it.grads, it.workspace,
-                                        it.workspace_bytes, stream);
+        const int rc = mbconv_bwd_impl(it.desc, in, it.act_buf, it.stat_buf, g, it.dx, it.tmp_buf, it.grads, it.workspace,
+                                       it.workspace_bytes, stream, prezeroed);
         if (rc) return rc;
         g = it.dx;
     }
     return OFASR_OK;
+}
+
+OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, const void* act_buf, const float* stat_buf,
+                                  const void* dout, void* dx, void* tmp_buf, const ofasr_mbconv_grads* g,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    return mbconv_bwd_impl(d, x, act_buf, stat_buf, dout, dx, tmp_buf, g, workspace, workspace_bytes, stream, false);
 }
 
 OFASR_EXPORT int ofasr_debug_mbconv_bn_bwd_stat(int enable) {

@@ -841,6 +841,7 @@ class FusedMBConvFn(Function):
 # descriptors are cached per (block, sub-network, shape) and the buffers of all blocks are slices of three allocations.
 FUSED_STACK = os.environ.get("OFASR_MBSTACK", "1") != "0"
 _DESC_CACHE = {}
+_PLAN_CACHE = {}
 _ALIGN = 256
 
 
@@ -919,68 +920,87 @@ class FusedMBStackFn(Function):
         return out
 
     @staticmethod
+    def _plan(metas, N, H, W, es):
+        """layout of the backward buffers (a function of the descriptors only; cached with them): per block the offset of
+        its tmp scratch, and the flat fp32 gradient buffer [w1 | w2 | wdw | dg1 | db1 | dg2 | db2 | dg3 | db3 | mats...]"""
+        key = (N, H, W, es) + tuple((id(m[0]), m[0].mid, m[0].Cout, len(m[7])) for m in metas)
+        hit = _PLAN_CACHE.get(key)
+        if hit is None:
+            tmp_off, tmp_b, sizes, shapes, g_off, g_n = [], 0, [], [], [], 0
+            for (d, a0, act_n, s0, stat_n, w0, ws_n, ps) in metas:
+                tmp_off.append(tmp_b)
+                tmp_b += _round_up(N * H * W * (3 * d.mid + d.Cout) * es)
+                w1, g1, b1, wdw, g2, b2, w2, g3, b3 = ps[:9]
+                sz = [w1.numel(), w2.numel(), wdw.numel()] + [g1.numel()] * 2 + [g2.numel()] * 2 + [g3.numel()] * 2 + \
+                    [m.numel() for m in ps[9:]]
+                offs, o = [], g_n
+                for n_ in sz:
+                    offs.append(4 * o)
+                    o += n_
+                g_off.append(offs)
+                g_n = o
+                sizes.extend(sz)
+                shapes.append((tuple(w1.shape), tuple(w2.shape), tuple(wdw.shape), [tuple(m.shape) for m in ps[9:]]))
+            hit = (tmp_off, tmp_b, sizes, shapes, g_off, g_n)
+            if len(_PLAN_CACHE) > 1024:
+                _PLAN_CACHE.clear()
+            _PLAN_CACHE[key] = hit
+        return hit
+
+    @staticmethod
     @once_differentiable
     def backward(ctx, dout):
         x, pool, *params = ctx.saved_tensors
         items, metas, bns, _ = ctx.stack
         L = _C.lib()
         N, C, H, W = x.shape
-        es = x.element_size()
         n = len(metas)
         dout = dout.contiguous()
-        # per block: tmp scratch, the dense gradient buffers (one fp32 allocation, zeroed by the library block by block),
-        # and dx -- two alternating buffers (dx is only read on this stream) plus the stack's own
-        tmp_b, tmp_off, g_off, g_n = 0, [], [], 0
-        for (d, *_rest) in metas:
-            tmp_off.append(tmp_b)
-            tmp_b += _round_up(N * H * W * (3 * d.mid + d.Cout) * es)
+        tmp_off, tmp_b, sizes, shapes, g_off, g_n = FusedMBStackFn._plan(metas, N, H, W, x.element_size())
+        # per block: tmp scratch, the dense gradient buffers (ONE fp32 allocation for the whole stack, cleared by the
+        # library with one fill), and dx -- two alternating buffers (dx is only read on this stream) plus the stack's own
         tmp = _bwd_scratch(tmp_b, torch.uint8, x.device)
-        sizes_all = []
-        for (d, a0, act_n, s0, stat_n, w0, ws_n, ps) in metas:
-            w1, g1, b1, wdw, g2, b2, w2, g3, b3 = ps[:9]
-            sizes = [w1.numel(), w2.numel(), wdw.numel()] + [g1.numel()] * 2 + [g2.numel()] * 2 + [g3.numel()] * 2 + \
-                [m.numel() for m in ps[9:]]
-            sizes_all.append(sizes)
-            g_off.append(g_n)
-            g_n += sum(sizes)
         flat = torch.empty(g_n, dtype=torch.float32, device=x.device)
+        parts = flat.split(sizes)
         dx = torch.empty_like(x)
         pp = [torch.empty_like(x), torch.empty_like(x)] if n > 1 else []
-        gstructs, grads_out, deferred_pairs = [], [None, None], []
         all_leaf = all(p.is_leaf for (_, _, _, _, _, _, _, ps) in metas for p in (ps[0], ps[3], ps[6]) + tuple(ps[9:]))
         defer = all_leaf and _defer_this_backward(())
         _set_lib_defer(defer)
         need = ctx.needs_input_grad
-        pi = 2
-        fb = flat.data_ptr()
+        fb, tb = flat.data_ptr(), tmp.data_ptr()
+        dxp = [dx.data_ptr()] + [pp[i & 1].data_ptr() for i in range(1, n)]
+        gstructs, grads_out, deferred_pairs = [], [None, None], []
+        pi, k = 2, 0
         for i, (d, a0, act_n, s0, stat_n, w0, ws_n, ps) in enumerate(metas):
-            sizes = sizes_all[i]
-            parts = flat[g_off[i]:g_off[i] + sum(sizes)].split(sizes)
-            w1, g1, b1, wdw, g2, b2, w2, g3, b3 = ps[:9]
-            mats = ps[9:]
-            dw1, dw2, dwdw = parts[0].view_as(w1), parts[1].view_as(w2), parts[2].view_as(wdw)
-            dmats = [parts[9 + j].view_as(mats[j]) for j in range(len(mats))]
+            offs = g_off[i]
+            nm = len(ps) - 9
             g = _C.MBConvGrads()
-            g.dw1, g.dw2, g.dwdw_max = dw1.data_ptr(), dw2.data_ptr(), dwdw.data_ptr()
-            for j, m in enumerate(dmats):
-                g.dmats[j] = m.data_ptr()
+            g.dw1, g.dw2, g.dwdw_max = fb + offs[0], fb + offs[1], fb + offs[2]
+            for j in range(nm):
+                g.dmats[j] = fb + offs[9 + j]
             for j in range(3):
-                g.dgamma[j], g.dbeta[j] = parts[3 + 2 * j].data_ptr(), parts[4 + 2 * j].data_ptr()
+                g.dgamma[j], g.dbeta[j] = fb + offs[3 + 2 * j], fb + offs[4 + 2 * j]
             gstructs.append(g)
             it = items[i]
-            it.tmp_buf = tmp.data_ptr() + tmp_off[i]
+            it.tmp_buf = tb + tmp_off[i]
             it.grads = ctypes.addressof(g)
-            it.dx = dx.data_ptr() if i == 0 else pp[i & 1].data_ptr()
-            # gradients in input order: w1, g1, b1, wdw, g2, b2, w2, g3, b3, *mats
-            wg = [dw1, parts[3], parts[4], dwdw, parts[5], parts[6], dw2, parts[7], parts[8]] + dmats
-            is_w = [True, False, False, True, False, False, True, False, False] + [True] * len(dmats)
-            for j, (gt, isw) in enumerate(zip(wg, is_w)):
-                if defer and isw:
+            it.dx = dxp[i]
+            pt = parts[k:k + 9 + nm]
+            k += 9 + nm
+            sh = shapes[i]
+            # gradients in input order: w1, g1, b1, wdw, g2, b2, w2, g3, b3, *mats (weights and matrices may be deferred)
+            order = ((0, sh[0]), (3, None), (4, None), (2, sh[2]), (5, None), (6, None), (1, sh[1]), (7, None), (8, None)) + \
+                tuple((9 + j, sh[3][j]) for j in range(nm))
+            for j, (src, shape) in enumerate(order):
+                if shape is None:
+                    grads_out.append(pt[src])
+                elif defer:
                     if need[pi + j]:
-                        deferred_pairs.append((ps[j], gt))
+                        deferred_pairs.append((ps[j], pt[src].view(shape)))
                     grads_out.append(None)
                 else:
-                    grads_out.append(gt)
+                    grads_out.append(pt[src].view(shape))
             pi += len(ps)
         with _timed("mbstack_bwd"):
             _C.check(L.ofasr_mbstack_bwd(items, n, _p(x), _p(dout), _stream()), "mbstack_bwd")
