@@ -112,7 +112,8 @@ class TrainWorkload(object):
         no_decay = list(net.get_parameters(["bn", "bias"], mode="include"))
         self.opt = torch.optim.Adam([{"params": decay, "weight_decay": 3e-5}, {"params": no_decay, "weight_decay": 0}],
                                     lr=1e-3, fused=True if os.environ.get("OFASR_FUSED_ADAM", "1") != "0" else None)
-        self.reducer = M["distributed"].FlatGradReducer(net.parameters(), gather=True) if world > 1 else None
+        early = net.early_gradient_parameters() if os.environ.get("OFASR_DP_OVERLAP", "0") != "0" else None
+        self.reducer = M["distributed"].FlatGradReducer(net.parameters(), gather=True, early_params=early) if world > 1 else None
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
         hr = torch.rand((batch, 3, self.scale * lr_size, self.scale * lr_size), generator=g)
         lr = F.interpolate(hr, scale_factor=1.0 / self.scale, mode="bicubic", antialias=True).clamp_(0, 1)
@@ -140,6 +141,8 @@ class TrainWorkload(object):
             with torch.autocast("cuda", dtype=self.act_dtype):
                 out = self.net(self.lr)
             loss = F.mse_loss(out.float(), self.hr)
+        if self.reducer is not None:
+            self.reducer.arm()           # (a no-op without OFASR_DP_OVERLAP=1: two-bucket overlapped exchange)
         loss.backward()
         self.M["ops"].flush_deferred()   # the MB blocks' weight gradients: one join of the side stream per backward pass
         if self.reducer is not None:

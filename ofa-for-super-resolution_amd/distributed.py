@@ -19,6 +19,14 @@ import torch
 import torch.distributed as dist
 
 
+class _null_ctx(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
@@ -63,13 +71,29 @@ class FlatGradReducer(object):
             optimizer.step()
     """
 
-    def __init__(self, params, process_group=None, gather=False):
+    def __init__(self, params, process_group=None, gather=False, early_params=None):
         # gather=False: every .grad is a view of the bucket during backward (autograd accumulates into it: one small
         #   add per parameter and backward node).  gather=True: backward runs with .grad = None (autograd hands the
         #   gradient tensors over without a kernel); reduce() zeroes the bucket and copies all gradients in with ONE
         #   multi-tensor copy -- ~250 fewer launches per step on the GPU, same result, same .grad views afterwards.
+        # early_params (needs gather=True): TWO buckets.  The gradients of `early_params` -- the decoder tail, whose backward
+        #   runs first -- are copied into the front of the flat buffer and all-reduced (async, on the communication stream
+        #   behind the library's side stream) as soon as the backward pass reaches ops.grad_milestone("decoder_tail"),
+        #   i.e. while the MB stack's backward still runs; reduce() exchanges the rest and waits for the first.  Armed per
+        #   backward pass with arm() (only the LAST pass of a gradient-accumulation step may start the exchange).  Element
+        #   by element the result equals the single bucket's.
         self.gather = bool(gather)
-        self.params = [p for p in params if p.requires_grad]
+        params = [p for p in params if p.requires_grad]
+        self.n_early = 0
+        if early_params is not None:
+            if not self.gather:
+                raise ValueError("the overlapped two-bucket exchange works on gathered gradients (gather=True)")
+            ids = {id(p) for p in params}
+            early = [p for p in early_params if p.requires_grad and id(p) in ids]
+            eids = {id(p) for p in early}
+            params = early + [p for p in params if id(p) not in eids]
+            self.n_early = len(early)
+        self.params = params
         if not self.params:
             raise ValueError("FlatGradReducer needs at least one trainable parameter")
         dev = self.params[0].device
@@ -90,6 +114,11 @@ class FlatGradReducer(object):
         from . import ops
         self._ops = ops
         self._removers = [ops.register_deferred_grad_hook(p, self._make_hook(i)) for i, p in enumerate(self.params)]
+        self.early_elems = sum(p.numel() for p in self.params[:self.n_early])
+        self._armed, self._early = False, None
+        self._comm_side = None
+        if self.n_early:
+            self._removers.append(ops.register_grad_milestone("decoder_tail", self._on_tail))
 
     def _make_hook(self, i):
         def hook(_param):
@@ -112,6 +141,63 @@ class FlatGradReducer(object):
             p.grad = v
             self._touched[i] = False
 
+    def arm(self):
+        """the next backward pass is the last of this optimizer step: it may start the early exchange"""
+        self._armed = self.n_early > 0
+
+    def _on_tail(self):
+        """called from backward at the decoder-tail milestone: gather the early gradients and start their all-reduce"""
+        if not self._armed or self._early is not None:
+            return
+        self._armed = False
+        ops = self._ops
+        dev = self.flat.device
+        cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        side = ops._lib_side_stream(dev) if dev.type == "cuda" else None
+        if side is None and dev.type == "cuda":
+            if self._comm_side is None:
+                self._comm_side = torch.cuda.Stream(device=dev)
+            side = self._comm_side
+        early = self.params[:self.n_early]
+        eids = {id(p) for p in early}
+        # the tail's large-plane conv weight gradients are still pending on the library's side stream (ops._Deferred):
+        # they are consumed here, in that stream's order; their buffers stay alive until the flush
+        pend = {}
+        keep = []
+        for p, g in ops._Deferred.grads:
+            if id(p) in eids:
+                pend.setdefault(id(p), []).append(g)
+            else:
+                keep.append((p, g))
+        ops._Deferred.grads = keep
+        ctx = torch.cuda.stream(side) if side is not None else _null_ctx()
+        if side is not None:
+            side.wait_stream(cur)        # the tail's gradients computed on the caller's stream
+        with ctx, torch.no_grad():
+            E = self.early_elems
+            self.flat[:E].zero_()
+            touched, dst, src, add_dst, add_src = [], [], [], [], []
+            for p, v in zip(early, self.views):
+                parts = ([p.grad] if p.grad is not None else []) + pend.get(id(p), [])
+                touched.append(bool(parts))
+                if parts:
+                    dst.append(v)
+                    src.append(parts[0])
+                    for extra in parts[1:]:
+                        add_dst.append(v)
+                        add_src.append(extra)
+            if dst:
+                torch._foreach_copy_(dst, src)
+            if add_dst:
+                torch._foreach_add_(add_dst, add_src)
+            for p, v, t in zip(early, self.views, touched):
+                if t:
+                    p.grad = v
+            work = None
+            if is_distributed():
+                work = dist.all_reduce(self.flat[:E], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._early = (work, touched, side, (src, add_src))
+
     def touched_mask(self):
         return list(self._touched)
 
@@ -119,6 +205,36 @@ class FlatGradReducer(object):
         """one all-reduce over the whole bucket; afterwards parameters that received no gradient in
         this step have .grad None (so Adam skips them, as in the reference)."""
         self._ops.flush_deferred()    # the deferred weight gradients of the backward pass(es) land in .grad first
+        self._armed = False
+        if self._early is not None:
+            # two buckets: the early one is in flight (or done); gather and exchange the rest, then wait for it
+            work, early_touched, side, _alive = self._early
+            self._early = None
+            E, ne = self.early_elems, self.n_early
+            rest, rviews = self.params[ne:], self.views[ne:]
+            self.flat[E:].zero_()
+            dst = [v for p, v in zip(rest, rviews) if p.grad is not None]
+            src = [p.grad for p in rest if p.grad is not None]
+            rest_touched = [p.grad is not None for p in rest]
+            if dst:
+                with torch.no_grad():
+                    torch._foreach_copy_(dst, src)
+            for p, v, t in zip(rest, rviews, rest_touched):
+                if t:
+                    p.grad = v
+            if is_distributed():
+                dist.all_reduce(self.flat[E:], op=dist.ReduceOp.SUM, group=self.group)
+            if work is not None:
+                work.wait()
+            if side is not None:
+                torch.cuda.current_stream(self.flat.device).wait_stream(side)
+            if is_distributed() and average:
+                self.flat.div_(dist.get_world_size(self.group))
+            self._touched = list(early_touched) + rest_touched
+            for p, t in zip(self.params, self._touched):
+                if not t:
+                    p.grad = None
+            return
         if self.gather:
             self.flat.zero_()
             dst = [v for p, v in zip(self.params, self.views) if p.grad is not None]

@@ -139,6 +139,8 @@ class OFAMobileNetS4(MobileNetS4):
         x = self.dec_first_conv_block(x)
         skip = x
         x = self._mb_stack(x)
+        # everything below is the decoder tail: in backward its gradients are complete when the pass comes back here
+        x = ops.grad_milestone(x, "decoder_tail")
         for i, conv in enumerate(self.dec_final_conv_blocks):
             x = conv(x)
             if i == 0:
@@ -146,6 +148,13 @@ class OFAMobileNetS4(MobileNetS4):
         for idx in self.block_group_info[_N_MB_STAGES][:self._shuffle_depth()]:
             x = self.blocks[idx](x)
         return self.dec_final_output_conv_block(x)
+
+    def early_gradient_parameters(self):
+        """the parameters behind ops.grad_milestone(..., "decoder_tail"): residual convs, conv + PixelShuffle blocks, RGB
+        head -- their gradients are final first in a backward pass (distributed.FlatGradReducer(early_params=...))"""
+        mods = list(self.dec_final_conv_blocks) + [self.blocks[i] for i in self.block_group_info[_N_MB_STAGES]] + \
+            [self.dec_final_output_conv_block]
+        return [p for m in mods for p in m.parameters()]
 
     @property
     def module_str(self):

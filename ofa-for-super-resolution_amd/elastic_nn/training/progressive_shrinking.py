@@ -134,6 +134,8 @@ def train_one_epoch(run_manager, args, epoch, warmup_epochs=0, warmup_lr=0):
                 loss = (args.kd_ratio * F.mse_loss(output, soft_logits) + loss) * (2 / (args.kd_ratio + 1))
             sub_losses.append(loss.detach())
             sub_psnrs.append(psnr_y_device(output, images))
+            if sub == args.dynamic_batch_size - 1:
+                run_manager.last_backward_next()
             loss.backward()
             ops.flush_deferred()   # the MB blocks' weight gradients: joined once per backward pass (ops.py)
         run_manager.step()

@@ -166,7 +166,13 @@ class SRRunManager(object):
         else:
             net_params = list(self.network.weight_parameters())
         self.optimizer = self.run_config.build_optimizer(net_params)
-        self.reducer = dd.FlatGradReducer(self.network.parameters(), gather=True) if dd.is_distributed() else None
+        # OFASR_DP_OVERLAP=1: two buckets, the decoder tail's exchanged while the MB stack's backward still runs
+        # (distributed.FlatGradReducer(early_params=...)); default: the single flat bucket
+        early = None
+        if os.environ.get("OFASR_DP_OVERLAP", "0") != "0" and hasattr(self.network, "early_gradient_parameters"):
+            early = self.network.early_gradient_parameters()
+        self.reducer = dd.FlatGradReducer(self.network.parameters(), gather=True, early_params=early) \
+            if dd.is_distributed() else None
 
     # ------------------------------------------------------------------ distributed helpers
     @property
@@ -179,6 +185,11 @@ class SRRunManager(object):
             self.reducer.prepare()
         else:
             self.optimizer.zero_grad(set_to_none=True)
+
+    def last_backward_next(self):
+        """the next backward pass is the last one before step(): the overlapped gradient exchange may start in it"""
+        if self.reducer is not None:
+            self.reducer.arm()
 
     def step(self):
         """gradient exchange (one flat all-reduce) + optimizer step."""

@@ -834,6 +834,43 @@ class FusedMBConvFn(Function):
         return (dx, None, dw1, dg1, db1, dwdw, dg2, db2, dw2, dg3, db3) + tuple(dmats)
 
 
+# ------------------------------------------------------------------------ backward milestones
+# A point of the network that, once its backward node runs, tells a registered listener that every gradient computed
+# "after" it in forward order has been issued (the data-parallel reducer starts exchanging the decoder tail's gradients
+# there, while the MB stack's backward still runs).  The node is only inserted while a listener is registered.
+_MILESTONES = {}
+
+
+def register_grad_milestone(tag, fn):
+    """fn() is called from backward when the pass reaches grad_milestone(x, tag); returns a remover"""
+    _MILESTONES[tag] = fn
+
+    def remove():
+        if _MILESTONES.get(tag) is fn:
+            del _MILESTONES[tag]
+    return remove
+
+
+class _MilestoneFn(Function):
+    @staticmethod
+    def forward(ctx, x, tag):
+        ctx.tag = tag
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        fn = _MILESTONES.get(ctx.tag)
+        if fn is not None:
+            fn()
+        return g, None
+
+
+def grad_milestone(x, tag):
+    if tag not in _MILESTONES or not torch.is_grad_enabled() or not x.requires_grad:
+        return x
+    return _MilestoneFn.apply(x, tag)
+
+
 # ------------------------------------------------------------------------------------ MB stack
 # All active MB blocks of the network in ONE autograd node and ONE foreign call per direction (ofasr_mbstack_fwd / _bwd).
 # Per block and direction the per-block path costs ~100 us of host time above the C ABI (module dispatch, autograd node,

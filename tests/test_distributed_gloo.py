@@ -129,3 +129,75 @@ def test_reducer_single_process_semantics():
             assert torch.equal(p.grad, w)
     assert net.a.weight.grad.data_ptr() == red2.flat.data_ptr()
     assert dd.world_size() == 1 and dd.rank() == 0 and not dd.is_distributed()
+
+
+class _Tail(nn.Module):
+    """toy net with the backward milestone of the S4 net: head / mid are the "decoder tail" (their backward runs first)"""
+
+    def __init__(self, ops):
+        super().__init__()
+        self.ops = ops
+        self.stem = nn.Linear(6, 6)
+        self.body = nn.Linear(6, 6)
+        self.mid = nn.Linear(6, 6)
+        self.head = nn.Linear(6, 2)
+        self.depth = 2
+
+    def forward(self, x):
+        x = torch.tanh(self.stem(x))
+        if self.depth > 1:
+            x = torch.tanh(self.body(x))
+        x = self.ops.grad_milestone(x, "decoder_tail")
+        return self.head(torch.tanh(self.mid(x)))
+
+    def early_gradient_parameters(self):
+        return list(self.mid.parameters()) + list(self.head.parameters())
+
+
+def _worker_overlap(rank, world, init_file, out_dir):
+    sys.path.insert(0, ROOT)
+    import importlib
+    dd = importlib.import_module(PKG + ".distributed")
+    ops = importlib.import_module(PKG + ".ops")
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    try:
+        torch.manual_seed(5)
+        net = _Tail(ops)
+        g = torch.Generator().manual_seed(11)
+        data = torch.randn(2, 2, 8, 6, generator=g)     # [step][rank][batch][feat]
+        tgt = torch.randn(2, 2, 8, 2, generator=g)
+        params = list(net.parameters())
+        results = []
+        for early in (None, net.early_gradient_parameters()):
+            red = dd.FlatGradReducer(params, gather=True, early_params=early)
+            got = []
+            for step, depth in enumerate([1, 2]):
+                net.depth = depth
+                red.prepare()
+                for sub in range(2):                     # two accumulation sub-steps: only the last may start the exchange
+                    if sub == 1:
+                        red.arm()
+                    nn.functional.mse_loss(net(data[step, rank]), tgt[step, rank]).backward()
+                    if early is not None:
+                        assert (red._early is not None) == (sub == 1), "early exchange started in the wrong pass"
+                red.reduce()
+                got.append([None if p.grad is None else p.grad.clone() for p in params])
+            red.remove()
+            results.append(got)
+        for a_step, b_step in zip(*results):
+            for a, b in zip(a_step, b_step):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert torch.equal(a, b), "two-bucket exchange != single bucket"
+        assert results[0][0][2] is None and results[0][1][2] is not None     # body skipped at depth 1
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_bucket_overlapped_exchange_equals_single_bucket_gloo():
+    """distributed.FlatGradReducer(early_params=...): the decoder tail's gradients are gathered and all-reduced from the
+    backward milestone (ops.grad_milestone) while the rest of the backward pass runs; bit for bit the single bucket."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_overlap, args=(2, os.path.join(d, "rendezvous"), d), nprocs=2, join=True)
+        assert os.path.exists(os.path.join(d, "ok0")) and os.path.exists(os.path.join(d, "ok1"))

@@ -149,3 +149,53 @@ def test_static_conv_weight_gradients_on_the_side_stream():
         assert (ref[n] is None) == (got[n] is None), n
         if ref[n] is not None:
             assert torch.equal(ref[n], got[n]), n
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, None])
+def test_mb_stack_call_equals_block_by_block(dtype):
+    """ops.FusedMBStackFn (one autograd node / foreign call for all active MB blocks, ofasr_mbstack_fwd / _bwd) against
+    the block-by-block path (ops.FusedMBConvFn per block): same kernels in the same order, so outputs, every gradient and
+    its None-ness, and the BN buffers are bit-identical; sampled sub-networks with skipped blocks, bf16 and fp32."""
+    ops, C = amd("ops"), amd("_C")
+    net = _net()
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    lr = torch.rand(2, 3, 32, 32, device=DEV)
+    hr = torch.rand(2, 3, 128, 128, device=DEV)
+
+    def run(stack):
+        was = ops.FUSED_STACK
+        ops.FUSED_STACK = stack
+        try:
+            net.load_state_dict(state)
+            net.zero_grad(set_to_none=True)
+            outs = []
+            for sub in range(2):                       # two sub-steps: gradients accumulate
+                random.seed(200 + sub)
+                net.sample_active_subnet()
+                C.reset_launch_counts()
+                if dtype is None:
+                    out = net(lr)
+                else:
+                    with torch.autocast("cuda", dtype=dtype):
+                        out = net(lr)
+                F.mse_loss(out.float(), hr).backward()
+                ops.flush_deferred()
+                outs.append(out.detach().float().clone())
+            torch.cuda.synchronize()
+            grads = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in net.named_parameters()}
+            bufs = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
+            return outs, grads, bufs
+        finally:
+            ops.FUSED_STACK = was
+
+    o1, g1, b1 = run(True)
+    o0, g0, b0 = run(False)
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    for n in g0:
+        assert (g0[n] is None) == (g1[n] is None), n
+        if g0[n] is not None:
+            assert torch.equal(g0[n], g1[n]), n
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
+    assert sum(g is None for g in g0.values()) > 0 and sum(g is not None for g in g0.values()) > 100

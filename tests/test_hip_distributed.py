@@ -100,7 +100,37 @@ def _worker(rank, world, init_file, out_dir):
         both = [torch.zeros_like(rm) for _ in range(world)]
         dist.all_gather(both, rm)
         assert not torch.equal(both[0], both[1])
+        single = [None if p.grad is None else p.grad.detach().clone() for p in params]
         reducer.remove()
+
+        # the two-bucket overlapped exchange (early_params = the decoder tail, started from the backward milestone while
+        # the MB stack's backward still runs) gives the single bucket's result bit for bit
+        net.load_state_dict(sd0)
+        net.zero_grad(set_to_none=True)
+        red2 = dd.FlatGradReducer(params, gather=True, early_params=net.early_gradient_parameters())
+        assert 0 < red2.n_early < len(red2.params) and red2.nbytes == reducer.nbytes
+        fired = []
+        orig = red2._on_tail
+        red2._on_tail = lambda: (fired.append(red2._armed), orig())[1]
+        red2._removers.append(ops.register_grad_milestone("decoder_tail", red2._on_tail))
+        red2.prepare()
+        for si, s in enumerate(seeds):
+            random.seed(s)
+            net.sample_active_subnet()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = net(lr[rank])
+            if si == len(seeds) - 1:
+                red2.arm()                           # only the last pass of the step may start the exchange
+            F.mse_loss(out.float(), hr[rank]).backward()
+            ops.flush_deferred()
+        assert fired == [False, True], fired
+        assert red2._early is not None, "the early bucket's exchange was not started from the backward pass"
+        red2.reduce()
+        for i, p in enumerate(params):
+            assert (p.grad is None) == (single[i] is None), i
+            if p.grad is not None:
+                assert torch.equal(p.grad, single[i]), "two-bucket exchange != single bucket (parameter %d)" % i
+        red2.remove()
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()
