@@ -27,6 +27,7 @@
 //                             64-channel X tile and the 128-row weight slab are staged once.
 //   fan-in  (any K, M <= 64 per pass) project fwd / expand dgrad: K is walked in 64-channel chunks
 //                             with the accumulators resident.
+#include <stdlib.h>
 #include "ofasr_common.h"
 
 namespace ofasr {
@@ -1394,6 +1395,112 @@ static WdPlan wd_plan(int64_t N, int64_t Cin, int64_t Cout, int64_t HW) {
     return p;
 }
 
+
+// ---- fp32 direct weight gradient (round 3): the scheme of pw_wgrad_direct_kernel on v_mfma_f32_32x32x2_f32.  A lane
+// (row, h) owns 16 consecutive pixels [32 u + 16 h, +16) of a 32-pixel unit -- four 16-byte requests per operand row,
+// straight from global memory, no LDS and no barrier -- and the unit's 16 matrix steps take element j of both lanes' runs
+// (k = h <-> pixel 32 u + 16 h + j: any bijection works as long as both operands use it).  The requests of unit u + 1
+// are issued before the 48 matrix instructions of unit u.  The staged kernel it replaces (LDS tiles, two barriers per
+// 128 pixels) ran at 123 us for the 384 x 64 gradient of a [16, ., 64, 64] block; the matrix floor is 20 us.
+struct WdPlan32 {
+    int units_per_img, total_units, nsplit, MR, NS;
+};
+
+__global__ void __launch_bounds__(512) pw_wgrad_direct_f32_kernel(const float* __restrict__ R, const float* __restrict__ S,
+                                                                  float* __restrict__ part, int MR, int NS, int HW,
+                                                                  WdPlan32 wp) {
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wr = wave & 3, wc = wave >> 2;
+    const int c = lane & 31, h = lane >> 5;
+    const int split = blockIdx.x;
+    const int row0 = blockIdx.y * WD_ROWS + wr * (WD_RB * 32);
+    const int col = blockIdx.z * WD_COLS + wc * 32 + c;
+    if (row0 >= MR) return;   // (no barrier in this kernel)
+    f32x16 acc[WD_RB];
+#pragma unroll
+    for (int rb = 0; rb < WD_RB; ++rb) acc[rb] = zero16();
+    const int u0 = (int)((long long)split * wp.total_units / wp.nsplit);
+    const int u1 = (int)((long long)(split + 1) * wp.total_units / wp.nsplit);
+    const bool cs = col < NS;
+    const int colc = cs ? col : NS - 1;
+    bool rs[WD_RB];
+    long long rowoff[WD_RB];
+#pragma unroll
+    for (int rb = 0; rb < WD_RB; ++rb) {
+        rs[rb] = row0 + 32 * rb + c < MR;
+        rowoff[rb] = (long long)(rs[rb] ? row0 + 32 * rb + c : MR - 1) * HW;
+    }
+    float4 a[2][WD_RB][4], b[2][4];
+    auto request = [&](int set, int u) {
+        const int uc = u < u1 ? u : u1 - 1;                   // beyond the range: re-request the last unit (contributes zero)
+        const int n = uc / wp.units_per_img;
+        const int px = (uc - n * wp.units_per_img) * 32 + 16 * h;
+        int pxc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pxc[j] = px + 4 * j < HW ? px + 4 * j : 0;
+        const float* sp = S + ((long long)n * NS + colc) * HW;
+        const float* rp = R + (long long)n * MR * HW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[set][j] = *reinterpret_cast<const float4*>(sp + pxc[j]);
+#pragma unroll
+        for (int rb = 0; rb < WD_RB; ++rb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[set][rb][j] = *reinterpret_cast<const float4*>(rp + rowoff[rb] + pxc[j]);
+    };
+    auto multiply = [&](int set, int u) {
+        const int n = u / wp.units_per_img;
+        const int px = (u - n * wp.units_per_img) * 32 + 16 * h;
+        const bool live = u < u1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = live && cs && px + 4 * j < HW;
+            const float4 bv = ok ? b[set][j] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int rb = 0; rb < WD_RB; ++rb) {
+                const float4 av = rs[rb] ? a[set][rb][j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[rb], 0, 0, 0);
+            }
+        }
+    };
+    if (u0 < u1) {
+        request(0, u0);
+        for (int u = u0; u < u1; u += 2) {     // whole pairs: straight-line body, two named register sets
+            request(1, u + 1);
+            multiply(0, u);
+            request(0, u + 2);
+            multiply(1, u + 1);
+        }
+    }
+    float* dst = part + (long long)split * MR * NS;
+    if (cs) {
+#pragma unroll
+        for (int rb = 0; rb < WD_RB; ++rb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = row0 + 32 * rb + acc_row(reg, h);
+                if (r < MR) dst[(long long)r * NS + col] = acc[rb][reg];
+            }
+    }
+}
+
+static WdPlan32 wd_plan32(int64_t N, int64_t Cin, int64_t Cout, int64_t HW) {
+    WdPlan32 p;
+    p.MR = (int)(Cout >= Cin ? Cout : Cin);
+    p.NS = (int)(Cout >= Cin ? Cin : Cout);
+    p.units_per_img = (int)cdiv(HW, 32);
+    p.total_units = (int)(N * p.units_per_img);
+    const int64_t tiles = cdiv(p.MR, WD_ROWS) * cdiv(p.NS, WD_COLS);
+    int64_t want = 256 / (tiles > 0 ? tiles : 1);   // one 8-wave block per CU ...
+    if (want > p.total_units / 8) want = p.total_units / 8;   // ... but at least 8 units per slab written
+    if (want < 1) want = 1;
+    p.nsplit = (int)want;
+    return p;
+}
+
 struct WgradPlan {
     int stages_per_img, total_stages, nsplit, stages_per_split, MR, NS;
 };
@@ -1569,6 +1676,24 @@ static int launch_wgrad(const char* name, const void* dy, const void* x, float* 
     if constexpr (XF || BXM) {
         set_error("%s: fused input transform needs the aligned 16-bit kernel", name);
         return OFASR_ERR_UNSUPPORTED;
+    }
+    if constexpr (!Elem<T>::is16) {
+        // OFF by default (OFASR_PW_WGRAD_F32_DIRECT=1): 68 against 71.6 us per call in isolation, but the fp32 training step is
+        // 22.96 against 22.78 ms with it (two A/B pairs) -- a wave-load of 64 lanes in 32 different rows runs at about one
+        // lane per clock in the address path, which is what bounds this kernel, and it competes with the chain for that path
+        static const bool f32_direct = [] { const char* e = getenv("OFASR_PW_WGRAD_F32_DIRECT"); return e && e[0] == '1'; }();
+        if (al && f32_direct) {
+            const WdPlan32 wp = wd_plan32(N, Cin, Cout, HW);
+            dim3 grid((unsigned)wp.nsplit, (unsigned)cdiv(wp.MR, WD_ROWS), (unsigned)cdiv(wp.NS, WD_COLS));
+            OFASR_LAUNCH(pw_wgrad_direct_f32_kernel, grid, dim3(512), 0, st, (const float*)R, (const float*)S, ws, wp.MR, wp.NS,
+                         (int)HW, wp);
+            int rc = check_launch(name);
+            if (rc) return rc;
+            const long long tot = (long long)wp.MR * wp.NS;
+            OFASR_LAUNCH(pw_wgrad_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(64 * WR_ZL), 0, st, ws, dw, wp.MR, wp.NS,
+                         wp.nsplit, sr, ss);
+            return check_launch(name);
+        }
     }
     dim3 grid((unsigned)cdiv(p.MR, 64), (unsigned)cdiv(p.NS, 64), (unsigned)p.nsplit);
     if (al)
@@ -1807,6 +1932,8 @@ OFASR_EXPORT size_t ofasr_pwconv_wgrad_workspace(int64_t N, int64_t Cin, int64_t
     int ns = p4.nsplit > p2.nsplit ? p4.nsplit : p2.nsplit;
     const int nd = wd_plan(N, Cin, Cout, HW).nsplit;
     ns = nd > ns ? nd : ns;
+    const int nd32 = wd_plan32(N, Cin, Cout, HW).nsplit;
+    ns = nd32 > ns ? nd32 : ns;
     return (size_t)ns * (size_t)p4.MR * (size_t)p4.NS * sizeof(float);
 }
 
