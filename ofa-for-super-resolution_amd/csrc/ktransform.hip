@@ -141,6 +141,145 @@ __global__ void __launch_bounds__(256) kt_bwd_mat_kernel(const float* __restrict
     if (o < q * q && cl == 0) dM[o] = a;
 }
 
+
+// ---- batched forms (round 3): the kernel transforms of ALL blocks of an MB stack in one launch per phase.  Per step the
+// per-block launches were 14 + 14 + ~15 kernels of <= 17 us (0.5 ms of kernel time, 43 launch gaps); the work per block
+// is unchanged (the kernels below are the per-block kernels with a job lookup in front).
+constexpr int KT_MAXJOBS = 16;
+struct KtBatch {
+    int n;
+    int start[KT_MAXJOBS + 1];      // first workgroup of job j (prefix sums)
+    const float* w_max[KT_MAXJOBS];
+    float* f[KT_MAXJOBS];           // fwd: the active filter
+    const float* df[KT_MAXJOBS];    // bwd
+    float* dw_max[KT_MAXJOBS];
+    float* ws[KT_MAXJOBS];
+    int C[KT_MAXJOBS];
+    KtParams p[KT_MAXJOBS];
+};
+struct KtMatBatch {
+    int n;
+    int start[2 * KT_MAXJOBS + 1];
+    const float* G[2 * KT_MAXJOBS];
+    const float* CR[2 * KT_MAXJOBS];
+    float* dM[2 * KT_MAXJOBS];
+    int q[2 * KT_MAXJOBS];
+    int C[2 * KT_MAXJOBS];
+};
+
+template <typename B> __device__ __forceinline__ int kt_job_of(const B& b, int blk) {
+    int j = 0;
+    while (j + 1 < b.n && blk >= b.start[j + 1]) ++j;
+    return j;
+}
+
+__global__ void __launch_bounds__(64) kt_fwd_batch_kernel(KtBatch b) {
+    __shared__ float buf[2][KT_MAXQ];
+    const int j = kt_job_of(b, blockIdx.x);
+    const KtParams& p = b.p[j];
+    const int c = blockIdx.x - b.start[j], t = threadIdx.x;
+    const int kmax = p.ks[0], K = p.ks[p.nsteps];
+    const float* wr = b.w_max[j] + (int64_t)c * kmax * kmax;
+    float* f = b.f[j];
+    if (!p.transform || p.nsteps == 0) {
+        for (int e = t; e < K * K; e += 64) f[(int64_t)c * K * K + e] = wr[crop_index(kmax, K, e)];
+        return;
+    }
+    for (int e = t; e < kmax * kmax; e += 64) buf[0][e] = wr[e];
+    __syncthreads();
+    int cur = 0, kc = kmax;
+    for (int s = 0; s < p.nsteps; ++s) {
+        const int kt = p.ks[s + 1], q = kt * kt;
+        const float* M = p.mats[s];
+        for (int o = t; o < q; o += 64) {
+            float a = 0.f;
+            for (int u = 0; u < q; ++u) a = fmaf(buf[cur][crop_index(kc, kt, u)], M[o * q + u], a);
+            buf[cur ^ 1][o] = a;
+        }
+        __syncthreads();
+        cur ^= 1;
+        kc = kt;
+    }
+    for (int e = t; e < K * K; e += 64) f[(int64_t)c * K * K + e] = buf[cur][e];
+}
+
+__global__ void __launch_bounds__(64) kt_bwd_chain_batch_kernel(KtBatch b) {
+    __shared__ float filt[KT_MAXSTEPS + 1][KT_MAXQ];
+    __shared__ float g[2][KT_MAXQ];
+    const int j = kt_job_of(b, blockIdx.x);
+    const KtParams& p = b.p[j];
+    const int C = b.C[j];
+    const int c = blockIdx.x - b.start[j], t = threadIdx.x;
+    const int kmax = p.ks[0], K = p.ks[p.nsteps];
+    const float* wr = b.w_max[j] + (int64_t)c * kmax * kmax;
+    const float* df = b.df[j];
+    float* dwr = b.dw_max[j] + (int64_t)c * kmax * kmax;
+    float* ws = b.ws[j];
+    if (!p.transform || p.nsteps == 0) {
+        const int s0 = kmax / 2 - K / 2;
+        for (int e = t; e < kmax * kmax; e += 64) {
+            const int a = e / kmax - s0, bb = e % kmax - s0;
+            dwr[e] = (a >= 0 && a < K && bb >= 0 && bb < K) ? df[(int64_t)c * K * K + a * K + bb] : 0.f;
+        }
+        return;
+    }
+    for (int e = t; e < kmax * kmax; e += 64) filt[0][e] = wr[e];
+    __syncthreads();
+    for (int s = 0; s < p.nsteps; ++s) {
+        const int kt = p.ks[s + 1], q = kt * kt, kc = p.ks[s];
+        const float* M = p.mats[s];
+        for (int o = t; o < q; o += 64) {
+            float a = 0.f;
+            for (int u = 0; u < q; ++u) a = fmaf(filt[s][crop_index(kc, kt, u)], M[o * q + u], a);
+            filt[s + 1][o] = a;
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < K * K; e += 64) g[0][e] = df[(int64_t)c * K * K + e];
+    __syncthreads();
+    int cur = 0;
+    for (int s = p.nsteps - 1; s >= 0; --s) {
+        const int kt = p.ks[s + 1], q = kt * kt, kc = p.ks[s];
+        const float* M = p.mats[s];
+        float* G = ws + p.ws_off[s] + (int64_t)c * q;
+        float* CR = ws + p.ws_off[s] + (int64_t)C * q + (int64_t)c * q;
+        for (int e = t; e < q; e += 64) {
+            G[e] = g[cur][e];
+            CR[e] = filt[s][crop_index(kc, kt, e)];
+        }
+        const int s0 = kc / 2 - kt / 2;
+        for (int e = t; e < kc * kc; e += 64) {
+            const int a = e / kc - s0, bb = e % kc - s0;
+            float v = 0.f;
+            if (a >= 0 && a < kt && bb >= 0 && bb < kt) {
+                const int u = a * kt + bb;
+                for (int o = 0; o < q; ++o) v = fmaf(g[cur][o], M[o * q + u], v);
+            }
+            g[cur ^ 1][e] = v;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (int e = t; e < kmax * kmax; e += 64) dwr[e] = g[cur][e];
+}
+
+__global__ void __launch_bounds__(256) kt_bwd_mat_batch_kernel(KtMatBatch b) {
+    const int j = kt_job_of(b, blockIdx.x);
+    const int q = b.q[j], C = b.C[j];
+    const float* G = b.G[j];
+    const float* CR = b.CR[j];
+    const int o = (blockIdx.x - b.start[j]) * 16 + (threadIdx.x >> 4);
+    const int cl = threadIdx.x & 15;
+    float a = 0.f;
+    if (o < q * q) {
+        const int t = o / q, u = o % q;
+        for (int c = cl; c < C; c += 16) a = fmaf(G[(int64_t)c * q + t], CR[(int64_t)c * q + u], a);
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) a += __shfl_xor(a, off, 16);
+    if (o < q * q && cl == 0) b.dM[j][o] = a;
+}
+
 static int fill_params(const char* name, KtParams& p, const int* ks, int nsteps, const float* const* mats,
                        int transform, int64_t C) {
     OFASR_REQUIRE(ks != nullptr, OFASR_ERR_INVALID_ARG, "%s: ks is null", name);
@@ -166,6 +305,81 @@ static int fill_params(const char* name, KtParams& p, const int* ks, int nsteps,
             p.mats[s] = mats[s];
         }
     return OFASR_OK;
+}
+
+
+int ktransform_fwd_batch(const KtJob* jobs, int n, void* stream) {
+    const char* name = "ktransform_fwd_batch";
+    OFASR_REQUIRE(jobs && n > 0 && n <= KT_MAXJOBS, OFASR_ERR_INVALID_ARG, "%s: bad job list", name);
+    KtBatch b{};
+    b.n = n;
+    int blocks = 0;
+    for (int j = 0; j < n; ++j) {
+        int rc = fill_params(name, b.p[j], jobs[j].ks, jobs[j].nsteps, jobs[j].mats, jobs[j].transform, jobs[j].C);
+        if (rc) return rc;
+        OFASR_REQUIRE(jobs[j].w_max && jobs[j].f && jobs[j].C > 0, OFASR_ERR_INVALID_ARG, "%s: job %d incomplete", name, j);
+        b.start[j] = blocks;
+        b.w_max[j] = jobs[j].w_max;
+        b.f[j] = jobs[j].f;
+        b.C[j] = (int)jobs[j].C;
+        blocks += (int)jobs[j].C;
+    }
+    b.start[n] = blocks;
+    OFASR_LAUNCH(kt_fwd_batch_kernel, dim3((unsigned)blocks), dim3(64), 0, as_stream(stream), b);
+    return check_launch(name);
+}
+
+int ktransform_bwd_batch(const KtJob* jobs, int n, void* stream) {
+    const char* name = "ktransform_bwd_batch";
+    OFASR_REQUIRE(jobs && n > 0 && n <= KT_MAXJOBS, OFASR_ERR_INVALID_ARG, "%s: bad job list", name);
+    KtBatch b{};
+    KtMatBatch m{};
+    b.n = n;
+    int blocks = 0, mblocks = 0;
+    for (int j = 0; j < n; ++j) {
+        const KtJob& jb = jobs[j];
+        int rc = fill_params(name, b.p[j], jb.ks, jb.nsteps, jb.mats, jb.transform, jb.C);
+        if (rc) return rc;
+        OFASR_REQUIRE(jb.w_max && jb.df && jb.dw_max && jb.C > 0, OFASR_ERR_INVALID_ARG, "%s: job %d incomplete", name, j);
+        const bool chain = b.p[j].transform && jb.nsteps > 0;
+        if (chain) {
+            const size_t need = ofasr_ktransform_bwd_workspace(jb.ks, jb.nsteps, jb.C);
+            OFASR_REQUIRE(jb.ws && jb.ws_bytes >= need, OFASR_ERR_WORKSPACE, "%s: job %d workspace %zu B < required %zu B", name, j,
+                          jb.ws_bytes, need);
+            int64_t off = 0;
+            for (int s = 0; s < jb.nsteps; ++s) {
+                OFASR_REQUIRE(jb.dmats && jb.dmats[s], OFASR_ERR_INVALID_ARG, "%s: job %d dmats[%d] is null", name, j, s);
+                b.p[j].dmats[s] = jb.dmats[s];
+                b.p[j].ws_off[s] = off;
+                const int q = jb.ks[s + 1] * jb.ks[s + 1];
+                OFASR_REQUIRE(m.n < 2 * KT_MAXJOBS, OFASR_ERR_UNSUPPORTED, "%s: too many transform steps", name);
+                m.start[m.n] = mblocks;
+                m.G[m.n] = (const float*)jb.ws + off;
+                m.CR[m.n] = (const float*)jb.ws + off + (int64_t)jb.C * q;
+                m.dM[m.n] = jb.dmats[s];
+                m.q[m.n] = q;
+                m.C[m.n] = (int)jb.C;
+                mblocks += (int)cdiv((int64_t)q * q, 16);
+                ++m.n;
+                off += (int64_t)2 * jb.C * q;
+            }
+        }
+        b.start[j] = blocks;
+        b.w_max[j] = jb.w_max;
+        b.df[j] = jb.df;
+        b.dw_max[j] = jb.dw_max;
+        b.ws[j] = (float*)jb.ws;
+        b.C[j] = (int)jb.C;
+        blocks += (int)jb.C;
+    }
+    b.start[n] = blocks;
+    hipStream_t st = as_stream(stream);
+    OFASR_LAUNCH(kt_bwd_chain_batch_kernel, dim3((unsigned)blocks), dim3(64), 0, st, b);
+    int rc = check_launch(name);
+    if (rc || m.n == 0) return rc;
+    m.start[m.n] = mblocks;
+    OFASR_LAUNCH(kt_bwd_mat_batch_kernel, dim3((unsigned)mblocks), dim3(256), 0, st, m);
+    return check_launch(name);
 }
 
 }  // namespace ofasr

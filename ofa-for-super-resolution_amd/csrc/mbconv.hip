@@ -21,6 +21,10 @@ static bool bn_fold_enabled() {
     static const bool on = [] { const char* e = getenv("OFASR_MBCONV_BN_BWD_FOLD"); return !(e && e[0] == '0'); }();
     return on;
 }
+// set by ofasr_mbstack_fwd / _bwd around their per-block calls: the stack runs the kernel transforms of all blocks in one
+// launch per phase itself (bit 0: the active filter is already in stat_buf; bit 1: leave the filter gradient's chain to the
+// caller)
+static thread_local int t_skip_kt = 0;
 static std::atomic<int> g_bn_bwd_stat{[] { const char* e = getenv("OFASR_MBCONV_BN_BWD_STAT"); return (e && e[0] == '1') ? 1 : 0; }()};
 
 struct MbSizes {
@@ -311,7 +315,8 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
             rc = pw_stat ? finalize(0, d->mid, P1, true) : pass_stats(0, y1, d->mid, true);
             if (rc) return rc;
         }
-        rc = ofasr_ktransform_fwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, f, d->mid, stream);
+        rc = (t_skip_kt & 1) ? OFASR_OK
+                             : ofasr_ktransform_fwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, f, d->mid, stream);
         if (rc) return rc;
         {
             StatView sv = stat_view(stat_buf, 0, d->mid, d->Cout);
@@ -358,7 +363,7 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
     rc = bn_forward(d, 0, y1, nullptr, a1, d->mid, 1, stat_buf, workspace, workspace_bytes, stream);
     if (rc) return rc;
     // active depthwise filter -> depthwise -> BN + ReLU6
-    rc = ofasr_ktransform_fwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, f, d->mid,
+    rc = (t_skip_kt & 1) ? OFASR_OK : ofasr_ktransform_fwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, f, d->mid,
                               stream);
     if (rc) return rc;
     rc = ofasr_dwconv_fwd(a1, f, y2, d->N, d->mid, d->H, d->W, d->K, d->dtype, stream);
@@ -605,8 +610,9 @@ static int mbconv_bwd_impl(const ofasr_mbconv_desc* d, const void* x, const void
             rc = dwconv_wgrad_xf(tC, y1, dfp, d->N, d->mid, d->H, d->W, d->K, d->dtype, xf_of(stat_buf, 0, d->mid, d->Cout),
                                  side_ws, s.side, sst);
         if (rc) return rc;
-        rc = ofasr_ktransform_bwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, dfp, g->dwdw_max, g->dmats,
-                                  d->mid, kt_ws, s.ws_kt + 256, sst);
+        rc = (t_skip_kt & 2) ? OFASR_OK
+                             : ofasr_ktransform_bwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, dfp, g->dwdw_max,
+                                                    g->dmats, d->mid, kt_ws, s.ws_kt + 256, sst);
         if (rc) return rc;
         if (coef_fold) {
             int P1 = 0;
@@ -648,8 +654,9 @@ static int mbconv_bwd_impl(const ofasr_mbconv_desc* d, const void* x, const void
     else
         rc = ofasr_dwconv_wgrad(tA, a1, dfp, d->N, d->mid, d->H, d->W, d->K, d->dtype, side_ws, s.side, sst);
     if (rc) return rc;
-    rc = ofasr_ktransform_bwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, dfp, g->dwdw_max, g->dmats,
-                              d->mid, kt_ws, s.ws_kt + 256, sst);
+    rc = (t_skip_kt & 2) ? OFASR_OK
+                         : ofasr_ktransform_bwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, dfp, g->dwdw_max,
+                                                g->dmats, d->mid, kt_ws, s.ws_kt + 256, sst);
     if (rc) return rc;
     rc = ofasr_dwconv_dgrad(tA, f, tB, d->N, d->mid, d->H, d->W, d->K, d->dtype, stream);
     if (rc) return rc;
@@ -703,22 +710,47 @@ static const void* stack_out_of(const ofasr_mbstack_item& it) {
     return (const char*)it.act_buf + (ofasr_mbconv_act_elems(d) - out_elems) * es;
 }
 
+static bool stack_kt_batch_enabled() {
+    static const bool on = [] { const char* e = getenv("OFASR_MBSTACK_KT_BATCH"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 OFASR_EXPORT int ofasr_mbstack_fwd(const ofasr_mbstack_item* items, int n, const void* x, void* stream) {
     OFASR_REQUIRE(items && n > 0 && x, OFASR_ERR_INVALID_ARG, "ofasr_mbstack_fwd: null / empty stack");
-    const void* in = x;
     for (int i = 0; i < n; ++i) {
-        const ofasr_mbstack_item& it = items[i];
-        OFASR_REQUIRE(it.desc != nullptr, OFASR_ERR_INVALID_ARG, "ofasr_mbstack_fwd: block %d has no descriptor", i);
+        OFASR_REQUIRE(items[i].desc != nullptr && items[i].stat_buf != nullptr, OFASR_ERR_INVALID_ARG,
+                      "ofasr_mbstack_fwd: block %d has no descriptor / statistics buffer", i);
         if (i > 0) {
-            const ofasr_mbconv_desc *a = items[i - 1].desc, *b = it.desc;
+            const ofasr_mbconv_desc *a = items[i - 1].desc, *b = items[i].desc;
             OFASR_REQUIRE(a->N == b->N && a->Cout == b->Cin && a->H == b->H && a->W == b->W && a->dtype == b->dtype,
                           OFASR_ERR_INVALID_ARG, "ofasr_mbstack_fwd: block %d does not take block %d's output", i, i - 1);
         }
-        const int rc = ofasr_mbconv_fwd(it.desc, in, it.act_buf, it.stat_buf, it.workspace, it.workspace_bytes, stream);
+    }
+    // the active depthwise filters of all blocks (centre crop + transform chain) in ONE launch, ahead of the blocks
+    const bool batch = stack_kt_batch_enabled() && n <= 16;
+    if (batch) {
+        KtJob jobs[16];
+        for (int i = 0; i < n; ++i) {
+            const ofasr_mbconv_desc* d = items[i].desc;
+            int rc = check_desc("ofasr_mbstack_fwd", d);
+            if (rc) return rc;
+            jobs[i] = KtJob{d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, d->mid,
+                            items[i].stat_buf + 8 * d->mid + 4 * d->Cout, nullptr, nullptr, nullptr, nullptr, 0};
+        }
+        int rc = ktransform_fwd_batch(jobs, n, stream);
         if (rc) return rc;
+    }
+    const void* in = x;
+    const int was = t_skip_kt;
+    if (batch) t_skip_kt |= 1;
+    int rc = OFASR_OK;
+    for (int i = 0; i < n && rc == OFASR_OK; ++i) {
+        const ofasr_mbstack_item& it = items[i];
+        rc = ofasr_mbconv_fwd(it.desc, in, it.act_buf, it.stat_buf, it.workspace, it.workspace_bytes, stream);
         in = stack_out_of(it);
     }
-    return OFASR_OK;
+    t_skip_kt = was;
+    return rc;
 }
 
 OFASR_EXPORT int ofasr_mbstack_bwd(const ofasr_mbstack_item* items, int n, const void* x, const void* dout, void* stream) {
@@ -758,17 +790,66 @@ OFASR_EXPORT int ofasr_mbstack_bwd(const ofasr_mbstack_item* items, int n, const
         }
     }
     const void* g = dout;
-    for (int i = n - 1; i >= 0; --i) {
+    const bool batch = stack_kt_batch_enabled() && n <= 16;
+    const int was = t_skip_kt;
+    if (batch) t_skip_kt |= 2;
+    int rc = OFASR_OK;
+    for (int i = n - 1; i >= 0 && rc == OFASR_OK; --i) {
         const ofasr_mbstack_item& it = items[i];
-        OFASR_REQUIRE(it.desc && it.dx && it.tmp_buf && it.grads, OFASR_ERR_INVALID_ARG,
-                      "ofasr_mbstack_bwd: block %d lacks a backward buffer", i);
+        if (!(it.desc && it.dx && it.tmp_buf && it.grads)) {
+            set_error("ofasr_mbstack_bwd: block %d lacks a backward buffer", i);
+            rc = OFASR_ERR_INVALID_ARG;
+            break;
+        }
         const void* in = i > 0 ? stack_out_of(items[i - 1]) : x;
-        const int rc = mbconv_bwd_impl(it.desc, in, it.act_buf, it.stat_buf, g, it.dx, it.tmp_buf, it.grads, it.workspace,
-                                       it.workspace_bytes, stream, prezeroed);
-        if (rc) return rc;
+        rc = mbconv_bwd_impl(it.desc, in, it.act_buf, it.stat_buf, g, it.dx, it.tmp_buf, it.grads, it.workspace,
+                             it.workspace_bytes, stream, prezeroed);
         g = it.dx;
     }
-    return OFASR_OK;
+    t_skip_kt = was;
+    if (rc || !batch) return rc;
+    // the filter gradients' way back through the transform chains (dense weight gradient + matrix gradients) of all blocks:
+    // two launches on the stream the depthwise weight gradients ran on, after the last of them
+    SideStream& ss = side_stream();
+    void* sst = ss.enabled ? (void*)ss.s : stream;
+    KtJob jobs[16];
+    for (int i = 0; i < n; ++i) {
+        const ofasr_mbconv_desc* d = items[i].desc;
+        const MbSizes sz = mb_sizes(d);
+        char* side_ws = (char*)items[i].workspace + sz.scratch;
+        jobs[i] = KtJob{d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, d->mid, nullptr,
+                        (const float*)(side_ws + sz.side), items[i].grads->dwdw_max, items[i].grads->dmats,
+                        side_ws + sz.side + sz.df_bytes, sz.ws_kt + 256};
+    }
+    rc = ktransform_bwd_batch(jobs, n, sst);
+    if (rc || !ss.enabled) return rc;
+    {
+        std::lock_guard<std::mutex> lk(ss.mu);
+        if (ss.defer) {   // one more entry behind the blocks': ofasr_mbconv_join orders this launch before the caller as well
+            const size_t k = ss.pending.size();
+            if (ss.pool.size() <= k) {
+                hipEvent_t ev = nullptr;
+                if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return join_side_locked(ss, as_stream(stream), "ofasr_mbstack_bwd");
+                }
+                ss.pool.push_back(ev);
+            }
+            const hipError_t e3 = hipEventRecord(ss.pool[k], ss.s);
+            OFASR_REQUIRE(e3 == hipSuccess, OFASR_ERR_LAUNCH, "ofasr_mbstack_bwd: event record failed: %s", hipGetErrorString(e3));
+            // (it reads every block's filter gradient and chain scratch: the span of the blocks' workspaces)
+            const char *wlo = nullptr, *whi = nullptr;
+            for (int i = 0; i < n; ++i) {
+                const char* w0 = (const char*)items[i].workspace;
+                wlo = (!wlo || w0 < wlo) ? w0 : wlo;
+                whi = (!whi || w0 + items[i].workspace_bytes > whi) ? w0 + items[i].workspace_bytes : whi;
+            }
+            ss.pending.push_back(PendingSide{nullptr, nullptr, wlo, whi, ss.pool[k]});
+        } else {
+            rc = join_side_locked(ss, as_stream(stream), "ofasr_mbstack_bwd");
+        }
+    }
+    return rc;
 }
 
 OFASR_EXPORT int ofasr_mbconv_bwd(const ofasr_mbconv_desc* d, const void* x, const void* act_buf, const float* stat_buf,

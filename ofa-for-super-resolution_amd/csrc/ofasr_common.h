@@ -345,6 +345,24 @@ int bn_fwd_cp(const void* x, const void* residual, void* y, const float2* partia
               const float* beta, float* running_mean, float* running_var, double momentum, double eps, int training,
               float* stats, int64_t N, int64_t C, int64_t HW, int act, int dtype, void* stream);
 
+// ktransform.hip: the kernel transforms of all blocks of an MB stack in one launch per phase (fwd: filter; bwd: chain + matrices)
+struct KtJob {
+    const float* w_max;
+    const int* ks;
+    int nsteps;
+    const float* const* mats;
+    int transform;
+    int64_t C;
+    float* f;                 // fwd
+    const float* df;          // bwd
+    float* dw_max;
+    float* const* dmats;
+    void* ws;
+    size_t ws_bytes;
+};
+int ktransform_fwd_batch(const KtJob* jobs, int n, void* stream);
+int ktransform_bwd_batch(const KtJob* jobs, int n, void* stream);
+
 // conv_thin.hip: the static convs with a 3-channel side (head / stem); conv2d.hip and conv2d_f32.hip route to them.
 // "out": the THIN tensor is the result (forward with Cout thin, input gradient with Cin thin);
 // "in": the THIN tensor is the operand; dgrad = 1 reads the [Cout][Cin][K][K] weights transposed and mirrored.

@@ -1388,7 +1388,8 @@ static WdPlan wd_plan(int64_t N, int64_t Cin, int64_t Cout, int64_t HW) {
     p.quads_per_img = (int)cdiv(HW, 64);
     p.total_quads = (int)(N * p.quads_per_img);
     const int64_t tiles = cdiv(p.MR, WD_ROWS) * cdiv(p.NS, WD_COLS);
-    int64_t want = 256 / (tiles > 0 ? tiles : 1);   // one 8-wave block per CU ...
+    static const int blocks = [] { const char* e = getenv("OFASR_PW_WGRAD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    int64_t want = blocks / (tiles > 0 ? tiles : 1);   // one 8-wave block per CU ...
     if (want > p.total_quads / 4) want = p.total_quads / 4;   // ... but at least 4 quads per slab written
     if (want < 1) want = 1;
     p.nsplit = (int)want;
