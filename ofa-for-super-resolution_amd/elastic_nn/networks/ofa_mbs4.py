@@ -136,6 +136,10 @@ class OFAMobileNetS4(MobileNetS4):
         return x
 
     def forward(self, x):
+        with ops.batched_counters():
+            return self._forward(x)
+
+    def _forward(self, x):
         x = self.dec_first_conv_block(x)
         skip = x
         x = self._mb_stack(x)

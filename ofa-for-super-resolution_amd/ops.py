@@ -1290,6 +1290,24 @@ CONV_BN_EPILOGUE = os.environ.get("OFASR_CONV_BN_EPILOGUE", "1") != "0"
 PS_BWD_FUSED = os.environ.get("OFASR_PS_BWD_FUSED", "1") != "0"   # BN backward reads dout through the inverse PixelShuffle
 
 
+class batched_counters(object):
+    """inside this context the `num_batches_tracked += 1` of the static ConvLayers' BatchNorms (one tiny launch each on
+    the critical stream: 6 per S4 forward) are collected and applied by ONE multi-tensor add when the context exits
+    (OFAMobileNetS4.forward wraps itself in it; a ConvLayer called on its own keeps the immediate bump)"""
+    pending = None
+
+    def __enter__(self):
+        self.outer = batched_counters.pending
+        batched_counters.pending = []
+        return self
+
+    def __exit__(self, *exc):
+        lst, batched_counters.pending = batched_counters.pending, self.outer
+        if lst:
+            torch._foreach_add_(lst, 1)
+        return False
+
+
 def conv_bn_act_train(x, conv, bn, act):
     """training-mode ConvLayer: conv (BatchNorm statistics from its epilogue) -> BatchNorm apply (+ ReLU6, or with the
     PixelShuffle(2) as its store), act in {ACT_NONE, ACT_RELU6, ACT_PIXEL_SHUFFLE2}.  One pass less over the conv output
@@ -1306,7 +1324,10 @@ def conv_bn_act_train(x, conv, bn, act):
         return None
     factor = 0.0
     if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+        if batched_counters.pending is not None and bn.momentum is not None:
+            batched_counters.pending.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
         factor = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
     y, partial = Conv2dStatFn.apply(x, w)
     return BNActCPFn.apply(y, partial, bn.weight, bn.bias, bn.running_mean, bn.running_var, factor, bn.eps, act)

@@ -40,7 +40,11 @@ def main():
     rows = list(csv.DictReader(open(path)))
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
     names = [e[2] for e in ev]
-    opt = [i for i, n in enumerate(names) if "multi_tensor_apply" in n]
+    # the optimizer's launches delimit the steps: the fused Adam's multi-tensor kernels when present (other multi-tensor
+    # launches -- the batched BatchNorm counter bump in the forward -- must not split a step)
+    opt = [i for i, n in enumerate(names) if "multi_tensor_apply" in n and "Adam" in n]
+    if not opt:
+        opt = [i for i, n in enumerate(names) if "multi_tensor_apply" in n]
     ends = [i for j, i in enumerate(opt) if j == len(opt) - 1 or opt[j + 1] - i > 50]
     lo, hi = ends[-(nsteps + 1 + skip)] + 1, ends[-1 - skip] + 1
     sel = ev[lo:hi]

@@ -15,14 +15,17 @@ def main():
     rows = list(csv.DictReader(open(path)))
     qkey = "Stream_Id" if "Stream_Id" in rows[0] else "Queue_Id"
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r[qkey]) for r in rows)
-    opt = [i for i, e in enumerate(ev) if "multi_tensor_apply" in e[2]]
+    opt = [i for i, e in enumerate(ev) if "multi_tensor_apply" in e[2] and "Adam" in e[2]]
+    if not opt:
+        opt = [i for i, e in enumerate(ev) if "multi_tensor_apply" in e[2]]
     ends = [i for j, i in enumerate(opt) if j == len(opt) - 1 or opt[j + 1] - i > 50]
     bounds = ends[-(nsteps + 1 + skip):len(ends) - skip]
     per = collections.defaultdict(lambda: [0.0, 0.0, 0, 0.0])   # busy, tail gap, kernels, first-start offset
     for a, b in zip(bounds[:-1], bounds[1:]):
         sel = ev[a + 1:b + 1]
         t0 = sel[0][0]
-        first_adam = min(s for s, e, n, q in sel if "multi_tensor_apply" in n)
+        adam = [s for s, e, n, q in sel if "multi_tensor_apply" in n and "Adam" in n]
+        first_adam = min(adam) if adam else min(s for s, e, n, q in sel if "multi_tensor_apply" in n)
         last = collections.defaultdict(int)
         first = {}
         for s, e, n, q in sel:
