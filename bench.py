@@ -65,6 +65,10 @@ def parse(argv=None):
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                                                       "the N>1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-graphs", action="store_true", help="c5: eager launches instead of one hipGraph replay per bucket")
+    ap.add_argument("--graph-step", action="store_true",
+                    help="c2 (fixed sub-network): capture the whole training step into ONE hipGraph and replay it.  Bit-identical "
+                         "to eager steps (tests/test_bench_step.py) but SLOWER on this stack -- 4.13 against 3.62 ms per step: the "
+                         "replayed graph loses part of the two-stream overlap -- so it is not the default")
     ap.add_argument("--cpu-images", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args(argv)
@@ -84,7 +88,7 @@ def mods():
 class TrainWorkload(object):
     """the training step of configs c3 / c2: same objects for the timed leg, the fp32 leg and tests/test_bench_step.py"""
 
-    def __init__(self, M, config, dev, batch, lr_size, dtype, world=1, rank=0, h2d=False, seed=0):
+    def __init__(self, M, config, dev, batch, lr_size, dtype, world=1, rank=0, h2d=False, seed=0, graph_step=False):
         import torch
         import torch.nn.functional as F
         self.torch, self.F, self.M = torch, F, M
@@ -110,8 +114,14 @@ class TrainWorkload(object):
         # optimizer: Adam, weight decay 3e-5 except on names with 'bn' / 'bias' (sr_run_manager.py:180-191)
         decay = list(net.get_parameters(["bn", "bias"], mode="exclude"))
         no_decay = list(net.get_parameters(["bn", "bias"], mode="include"))
+        # c2's sub-network is FIXED, so every step launches the same kernels on the same buffers: with graph_step the whole
+        # step (forward, loss, backward, side-stream join, Adam) is captured once into a hipGraph and replayed (opt-in:
+        # measured slower than the eager step here); c3 samples a new sub-network per step (3^16 kernel-size assignments)
+        self.graph = None
+        self.want_graph = bool(graph_step) and self.fixed is not None and world == 1 and not h2d
         self.opt = torch.optim.Adam([{"params": decay, "weight_decay": 3e-5}, {"params": no_decay, "weight_decay": 0}],
-                                    lr=1e-3, fused=True if os.environ.get("OFASR_FUSED_ADAM", "1") != "0" else None)
+                                    lr=1e-3, fused=True if os.environ.get("OFASR_FUSED_ADAM", "1") != "0" else None,
+                                    capturable=self.want_graph)
         early = net.early_gradient_parameters() if os.environ.get("OFASR_DP_OVERLAP", "0") != "0" else None
         self.reducer = M["distributed"].FlatGradReducer(net.parameters(), gather=True, early_params=early) if world > 1 else None
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -122,7 +132,36 @@ class TrainWorkload(object):
         if self.fixed is not None:
             net.set_active_subnet(**self.fixed)
 
+    def capture(self):
+        """warm up eagerly on a side stream, then capture one whole training step; False when the capture fails (the
+        workload then stays eager)"""
+        torch = self.torch
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            for i in range(3):
+                self._eager_step(i)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize()
+        try:
+            g = torch.cuda.CUDAGraph()
+            self.opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(g):
+                self.static_loss = self._eager_step(0)
+            self.graph = g
+        except Exception as e:   # noqa: BLE001 -- a failed capture must not take the benchmark down
+            sys.stderr.write("whole-step capture failed (%s): eager steps\n" % (e,))
+            self.graph = None
+            torch.cuda.synchronize()
+        return self.graph is not None
+
     def step(self, i):
+        if self.graph is not None:
+            self.graph.replay()
+            return self.static_loss
+        return self._eager_step(i)
+
+    def _eager_step(self, i):
         torch, F = self.torch, self.F
         if self.hr_host is not None:   # what the reference's loader hands over: host tensors
             self.hr.copy_(self.hr_host, non_blocking=True)
@@ -408,8 +447,11 @@ def main():
             wl = EvalWorkload(M, dev, dtype, graphs=not args.no_graphs)
             per_step = wl.n_images
         else:
-            wl = TrainWorkload(M, args.config, dev, args.batch, S, dtype, world, rank, h2d)
+            wl = TrainWorkload(M, args.config, dev, args.batch, S, dtype, world, rank, h2d,
+                               graph_step=args.config == "c2" and args.graph_step)
             per_step = args.batch
+            if wl.want_graph:
+                wl.capture()
         dt, last = timed(wl.step, warmup, steps, fence)
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -421,12 +463,14 @@ def main():
         if not args.no_roofline:   # every rank runs the profiled steps (they contain the gradient all-reduce); rank 0 reports
             nprof = min(steps, 6)
             # (a replayed graph runs no host code, so the per-dispatch events need the eager launches of the same kernels)
-            prof_step = (lambda i: wl.step(i, eager=True)) if args.config == "c5" else wl.step
+            prof_step = (lambda i: wl.step(i, eager=True)) if args.config == "c5" else \
+                (wl._eager_step if getattr(wl, "graph", None) is not None else wl.step)
             summ = profile_steps(M, prof_step, warmup + steps, nprof)
             out["roofline"], out["kernels"], out["pointwise"] = roofline_from(summ, nprof, dtype)
         else:
             out["roofline"] = out["kernels"] = out["pointwise"] = None
         extra = {"n_params": wl.n_params, "buckets": len(wl.buckets) if args.config == "c5" else None,
+                 "graph_step": args.config != "c5" and getattr(wl, "graph", None) is not None,
                  "graphed": args.config == "c5" and wl.graphed is not None, "per_step": per_step}
         del wl
         torch.cuda.empty_cache()
@@ -464,7 +508,9 @@ def main():
                "kernel_transform_mode": 1, "compat_reference_indexing": True, "parallelism": "dp%d" % world}
         if args.config != "c5":
             cfg.update({"per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                        "grad_allreduce_bytes": 2160422 * 4 if world > 1 else 0, "final_loss": final_loss})
+                        "grad_allreduce_bytes": 2160422 * 4 if world > 1 else 0, "final_loss": final_loss,
+                        "launch": "one hipGraph replay per training step (fixed sub-network)" if info.get("graph_step")
+                        else "eager"})
             cfg.pop("params")
         else:
             cfg["images_per_pass"] = per_step

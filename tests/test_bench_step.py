@@ -41,3 +41,31 @@ def test_bench_train_step_losses_match_the_oracle_port(dtype, tol):
     # rounding-level gradient difference (fp32 summation order) is amplified step by step: 1e-7 / 5e-6 / 2.5e-4 measured
     for i, (a, b) in enumerate(zip(got, ref)):
         assert abs(a - b) <= tol * (1 + 4 * i) * abs(b), (dtype, got, ref)
+
+
+def test_config2_whole_step_graph_equals_eager_steps():
+    """bench.py --config c2 replays ONE captured hipGraph per training step (the sub-network is fixed: forward, loss,
+    backward on both streams, the side-stream join and the fused Adam are the same launches on the same buffers every
+    step).  Three eager warm-up steps + three replays must leave exactly the weights of six eager steps."""
+    import bench
+    dev = torch.device("cuda", 0)
+    M = bench.mods()
+
+    def run(capture):
+        wl = bench.TrainWorkload(M, "c2", dev, batch=4, lr_size=16, dtype="bf16", graph_step=True)
+        assert wl.want_graph
+        if capture:
+            assert wl.capture(), "the whole-step capture failed"
+            for i in range(3):
+                wl.step(3 + i)
+        else:
+            for i in range(6):
+                wl.step(i)
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in wl.net.state_dict().items()}, float(wl.step(9))
+
+    a, la = run(False)
+    b, lb = run(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert la == lb
