@@ -32,20 +32,24 @@ class GraphedEval(object):
         self.copy_output = copy_output
         self._graphs = collections.OrderedDict()
         self._epoch = ops.infer_epoch()
+        self._tensors = self._bns = None
         self.captures = 0
         self.replays = 0
 
     # ------------------------------------------------------------------ state the captured pointers depend on
     def _state(self):
         net = self.net
-        tensors = tuple((t.data_ptr(), t._version) for t in list(net.parameters()) + list(net.buffers()))
+        if self._tensors is None:     # the module tree is fixed: walk it once (this runs on every call)
+            self._tensors = list(net.parameters()) + list(net.buffers())
+            self._bns = [m for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+        tensors = tuple((t.data_ptr(), t._version) for t in self._tensors)
         try:
             arch = net.module_str
         except (AttributeError, NotImplementedError):
             arch = None
         # BN eps is folded into the prepared operands but is a plain float (set_bn_param rewrites it without touching
         # any tensor); the two switches select which kernels a forward launches
-        eps = tuple(m.eps for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm))
+        eps = tuple(m.eps for m in self._bns)
         # the operand cache's epoch: bumped by everything that rewrites weights behind the version counters
         return arch, hash(tensors), hash(eps), ops.FUSED_INFER, ops.INFER_CACHE, ops.infer_epoch()
 
