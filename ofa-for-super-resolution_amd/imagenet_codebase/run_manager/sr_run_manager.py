@@ -321,8 +321,8 @@ class SRRunManager(object):
         """`validate` with the loader's batch-1 items of EQUAL size run as one batch (BASELINE config 5: Set14 at
         full resolution, reference eval_ofa_net_sr.py:187-220,247-251 / sr_run_manager.py:323-393).  Loss and PSNR are
         taken per image, so the result equals `validate` on the batch-1 loader (tests/test_hip_configs.py).
-        `graphs` (default: on for 16-bit GPU inference unless OFASR_EVAL_GRAPHS=0): every size bucket's forward is captured once
-        as a hipGraph and replayed -- the per-launch host cost otherwise bounds this loop (graphed.py).
+        `graphs` (default: on for 16-bit GPU inference unless OFASR_EVAL_GRAPHS=0): the forwards of all size buckets are
+        captured once as ONE hipGraph and replayed -- the per-launch host cost otherwise bounds this loop (graphed.py).
         Returns (mean loss, mean PSNR, number of forward calls)."""
         if net is None:
             net = self.net
@@ -341,14 +341,17 @@ class SRRunManager(object):
                 items.append({k: v[i:i + 1] for k, v in mini_batch.items() if torch.is_tensor(v)})
         losses, psnrs, calls = AverageMeter(), AverageMeter(), 0
         with torch.no_grad():
-            for group in bucket_by_size(items, key=lambda it: it[input_key], max_batch=max_batch):
+            groups = list(bucket_by_size(items, key=lambda it: it[input_key], max_batch=max_batch))
+            lrs = [torch.cat([it[input_key] for it in group]).to(self.device) for group in groups]
+            # all size buckets of the pass in ONE captured graph / one replay (the validation set is the same every epoch)
+            outs = fwd.call_many(lrs) if (fwd is not None and lrs) else None
+            for gi, group in enumerate(groups):
                 images = torch.cat([it["image"] for it in group]).to(self.device)
-                lr = torch.cat([it[input_key] for it in group]).to(self.device)
-                if fwd is not None:
-                    output = fwd(lr).float()
+                if outs is not None:
+                    output = outs[gi].float()
                 else:
                     with self.autocast():
-                        output = net(lr).float()
+                        output = net(lrs[gi]).float()
                 calls += 1
                 per_img = ((output - images) ** 2).mean(dim=(1, 2, 3))
                 for v in per_img.tolist():

@@ -80,3 +80,20 @@ def test_graphed_eval_refuses_training_state():
     net.train()
     with torch.no_grad(), pytest.raises(RuntimeError):
         g(x)
+
+
+def test_call_many_one_graph_for_all_size_buckets():
+    """GraphedEval.call_many: the forwards of several differently sized inputs (one evaluation pass) captured as ONE graph and
+    replayed with one host call; outputs equal the eager forwards bit for bit, a second pass replays, new data flows through."""
+    G = amd("graphed")
+    net = _net()
+    g = G.GraphedEval(net, autocast_dtype=torch.bfloat16)
+    gen = torch.Generator().manual_seed(3)
+    sizes = [(2, 3, 24, 40), (1, 3, 31, 18), (3, 3, 16, 16)]
+    with torch.no_grad():
+        for rep in range(2):
+            xs = [torch.rand(s, generator=gen).to(DEV) for s in sizes]
+            ys = g.call_many(xs)
+            assert g.captures == 1 and g.replays == rep + 1
+            for x, y in zip(xs, ys):
+                assert torch.equal(y, _eager(net, x))
