@@ -160,6 +160,7 @@ class FlatGradReducer(object):
             side = self._comm_side
         early = self.params[:self.n_early]
         eids = {id(p) for p in early}
+        ops.launch_late_conv_wgrads()    # (held back until the MB stack's backward: they must be on the side stream now)
         # the tail's large-plane conv weight gradients are still pending on the library's side stream (ops._Deferred):
         # they are consumed here, in that stream's order; their buffers stay alive until the flush
         pend = {}

@@ -527,6 +527,7 @@ class _Deferred(object):
     grads = []          # (parameter, gradient) pairs to accumulate after the join
     ext = {}            # device index -> torch view of the library's side stream (None when it is disabled)
     ext_used = set()    # devices whose side stream got work from this module since the last flush
+    late = []           # launches of deferred static-conv weight gradients held back until the MB stack's backward starts
     hooks = {}          # id(parameter) -> [callables]: run after a deferred gradient has been accumulated
     opt_hook = None     # handle of the global optimizer-step pre-hook
 
@@ -565,9 +566,18 @@ def register_deferred_grad_hook(param, fn):
     return remove
 
 
+def launch_late_conv_wgrads():
+    """start the static-conv weight gradients that were held back (CONV_WGRAD_LATE) on the library's side stream"""
+    if _Deferred.late:
+        jobs, _Deferred.late = _Deferred.late, []
+        for job in jobs:
+            job()
+
+
 def flush_deferred():
     """join the library's side stream into the current stream, then accumulate the held weight gradients."""
     _Deferred.queued = False
+    launch_late_conv_wgrads()
     if not (_Deferred.keep or _Deferred.grads):
         return
     _C.check(_C.lib().ofasr_mbconv_join(_stream()), "mbconv_join")
@@ -993,6 +1003,7 @@ class FusedMBStackFn(Function):
         N, C, H, W = x.shape
         n = len(metas)
         dout = dout.contiguous()
+        launch_late_conv_wgrads()    # the decoder tail's weight gradients: beside this stack's bandwidth-bound chain
         tmp_off, tmp_b, sizes, shapes, g_off, g_n = FusedMBStackFn._plan(metas, N, H, W, x.element_size())
         # per block: tmp scratch, the dense gradient buffers (ONE fp32 allocation for the whole stack, cleared by the
         # library with one fill), and dx -- two alternating buffers (dx is only read on this stream) plus the stack's own
@@ -1063,6 +1074,10 @@ SIDE_STREAM = os.environ.get("OFASR_CONV_SIDE_STREAM", "0") != "0"
 # OFASR_CONV_DEFER_WGRAD=0 keeps them on the caller's stream.
 CONV_DEFER_WGRAD = os.environ.get("OFASR_CONV_DEFER_WGRAD", "1") != "0"
 CONV_DEFER_MIN_HW = int(os.environ.get("OFASR_CONV_DEFER_MIN_HW", "10000"))
+# deferred conv weight gradients held back until the MB stack's backward starts (beside bandwidth-bound kernels instead of
+# the tail's own matrix-bound ones).  Off: 2630-2663 against 2668-2682 images/s (two A/B pairs) -- the tail's BatchNorm
+# passes get faster, the MB chain slower by more
+CONV_WGRAD_LATE = os.environ.get("OFASR_CONV_WGRAD_LATE", "0") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -1261,13 +1276,23 @@ def _conv2d_backward(ctx, dy):
     if ctx.needs_input_grad[1]:
         dw = torch.empty_like(weight)
         wst2, wsp2, wsn2 = _ws(L.ofasr_conv2d_wgrad_workspace(N, Cin, Cout, H, W, K), x.device)
-        if side is not None:
-            side.wait_stream(cur)
-        with torch.cuda.stream(side if side is not None else cur):
-            with _timed("conv2d_wgrad_%dto%d_k%d" % (Cin, Cout, K), (x.numel() + dy.numel()) * x.element_size(),
-                        2 * N * H * W * Cin * Cout * K * K):
-                _C.check(L.ofasr_conv2d_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Cout, H, W, K, _dt(x), wsp2, wsn2,
-                                              _stream()), "conv2d_wgrad")
+        dt_code = _dt(x)
+
+        def launch_wgrad():
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side if side is not None else cur):
+                with _timed("conv2d_wgrad_%dto%d_k%d" % (Cin, Cout, K), (x.numel() + dy.numel()) * x.element_size(),
+                            2 * N * H * W * Cin * Cout * K * K):
+                    _C.check(L.ofasr_conv2d_wgrad(_p(dy), _p(x), _p(dw), N, Cin, Cout, H, W, K, dt_code, wsp2, wsn2,
+                                                  _stream()), "conv2d_wgrad")
+
+        if defer and CONV_WGRAD_LATE:
+            # (opt-in, measured slower) not now: launched when the backward pass reaches the MB stack
+            # (FusedMBStackFn.backward) or at the flush at the latest
+            _Deferred.late.append(launch_wgrad)
+        else:
+            launch_wgrad()
     if ctx.needs_input_grad[0]:
         dx = torch.empty_like(x)
         wst, wsp, wsn = _ws(L.ofasr_conv2d_workspace(Cin, Cout, K, 1), x.device)
