@@ -15,6 +15,7 @@
 //   bn_act_fwd      reads B*M*C (+B*M*C residual), writes B*M*C
 //   bn_bwd_reduce   reads 2*B*M*C
 //   bn_bwd_apply    reads 2*B*M*C, writes B*M*C
+#include <stdlib.h>
 #include "ofasr_common.h"
 
 namespace ofasr {
@@ -442,6 +443,86 @@ __global__ void __launch_bounds__(BN_THREADS) bn_bwd_apply_kernel(const T* __res
                 dx[off + i] = from_float<T>(k1 * (dz - ka - (xf - mu) * is * kb));
                 if (RES && dres) dres[off + i] = from_float<T>(dz);
             }
+        }
+    }
+}
+
+
+// ---- one-pass BatchNorm backward for SMALL channels (round 3): a channel whose N * HW elements fit the registers of one
+// 1024-thread workgroup (<= 65536 16-bit values: BN3 of every MB block and the 64-channel static convs at LR resolution,
+// 8 MB tensors) is reduced and applied by the SAME workgroup -- each thread keeps its <= 8 chunks of dy and x in registers
+// across the block-wide sum.  One launch instead of two and one pass over (dy, x) instead of two; on the input-gradient
+// chain every kernel boundary is a pipeline bubble, which is what the two 7 us kernels mostly were.  No activation, no
+// residual (the shapes above).  Sums: fp32 per thread (<= 64 values), fp64 across the workgroup in a fixed order.
+constexpr int BN1P_THREADS = 1024, BN1P_MAXCH = 8;
+template <typename T>
+__global__ void __launch_bounds__(BN1P_THREADS) bn_bwd_onepass_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                      T* __restrict__ dx, const float* __restrict__ scale,
+                                                                      const float* __restrict__ mean,
+                                                                      const float* __restrict__ invstd,
+                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                      int N, int C, int HW, double M, int training) {
+    __shared__ double red[2][BN1P_THREADS / 64];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int cpi = HW / 8;                 // 16-byte chunks per image plane
+    const int total = N * cpi;
+    const float mu = mean[c], is = invstd[c], k1 = scale[c];
+    uint4 dv[BN1P_MAXCH], xv[BN1P_MAXCH];
+    long long off[BN1P_MAXCH];
+#pragma unroll
+    for (int j = 0; j < BN1P_MAXCH; ++j) {
+        const int q = tid + j * BN1P_THREADS;
+        const int qc = q < total ? q : total - 1;        // (clamped request, zeroed below: no load under a branch)
+        const int n = qc / cpi, i = qc - n * cpi;
+        off[j] = ((long long)n * C + c) * HW + 8LL * i;
+        dv[j] = *reinterpret_cast<const uint4*>(dy + off[j]);
+        xv[j] = *reinterpret_cast<const uint4*>(x + off[j]);
+    }
+    float s = 0.f, sx = 0.f;
+#pragma unroll
+    for (int j = 0; j < BN1P_MAXCH; ++j) {
+        if (tid + j * BN1P_THREADS < total) {
+            float f[8], g[8];
+            unpack16<T>(xv[j], f);
+            unpack16<T>(dv[j], g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s += g[e];
+                sx += g[e] * ((f[e] - mu) * is);
+            }
+        }
+    }
+    double ds = (double)s, dsx = (double)sx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ds += __shfl_xor(ds, o, 64);
+        dsx += __shfl_xor(dsx, o, 64);
+    }
+    if ((tid & 63) == 0) {
+        red[0][tid >> 6] = ds;
+        red[1][tid >> 6] = dsx;
+    }
+    __syncthreads();
+    double ts = 0.0, tsx = 0.0;
+#pragma unroll
+    for (int w = 0; w < BN1P_THREADS / 64; ++w) {
+        ts += red[0][w];
+        tsx += red[1][w];
+    }
+    if (tid == 0) {
+        if (dgamma) dgamma[c] = (float)tsx;
+        if (dbeta) dbeta[c] = (float)ts;
+    }
+    const float ka = training ? (float)(ts / M) : 0.f, kb = training ? (float)(tsx / M) : 0.f;
+#pragma unroll
+    for (int j = 0; j < BN1P_MAXCH; ++j) {
+        if (tid + j * BN1P_THREADS < total) {
+            float f[8], g[8], o[8];
+            unpack16<T>(xv[j], f);
+            unpack16<T>(dv[j], g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = k1 * (g[e] - ka - (f[e] - mu) * is * kb);
+            *reinterpret_cast<uint4*>(dx + off[j]) = pack16<T>(o);
         }
     }
 }
@@ -934,6 +1015,26 @@ OFASR_EXPORT int ofasr_bn_act_bwd(const void* dy, const void* x, const void* res
     dim3 grid((unsigned)C, (unsigned)P);
     hipStream_t st = as_stream(stream);
     const bool v = vec_ok(HW, dtype, dy, x, residual, dx) && ((reinterpret_cast<uintptr_t>(dresidual) & 15) == 0);
+    {
+        // small channels: reduction and apply by one workgroup per channel from registers (bn_bwd_onepass_kernel)
+        // OFF by default (OFASR_BN_BWD_ONEPASS=1): in the training step 2604-2614 against 2686-2695 images/s (two A/B pairs)
+        // -- 64 workgroups of 1024 threads are a latency-bound kernel on a quarter of the CUs and cannot share them with the
+        // side stream's kernels; the two 7 us passes on the whole chip are shorter
+        static const bool onepass = [] { const char* e = getenv("OFASR_BN_BWD_ONEPASS"); return e && e[0] == '1'; }();
+        if (onepass && v && act == 0 && !residual && !dresidual && dtype != OFASR_F32 && HW % 8 == 0 &&
+            N * (HW / 8) <= (int64_t)BN1P_THREADS * BN1P_MAXCH && C <= 65535) {
+            prof_note(2.0 * (double)N * (double)C * (double)HW * 3.0, 0.0);       // reads dy, x; writes dx
+            if (dtype == OFASR_BF16)
+                OFASR_LAUNCH((bn_bwd_onepass_kernel<bf16_t>), dim3((unsigned)C), dim3(BN1P_THREADS), 0, st, (const bf16_t*)dy,
+                             (const bf16_t*)x, (bf16_t*)dx, scale, mean, invstd, dgamma, dbeta, (int)N, (int)C, (int)HW, M,
+                             training);
+            else
+                OFASR_LAUNCH((bn_bwd_onepass_kernel<f16_t>), dim3((unsigned)C), dim3(BN1P_THREADS), 0, st, (const f16_t*)dy,
+                             (const f16_t*)x, (f16_t*)dx, scale, mean, invstd, dgamma, dbeta, (int)N, (int)C, (int)HW, M,
+                             training);
+            return check_launch(name);
+        }
+    }
 #define OFASR_BNR(VEC, ACT, RES)                                                                                     \
     OFASR_LAUNCH((bn_bwd_reduce_kernel<T, VEC, ACT, RES>), grid, dim3(BN_THREADS), 0, st, (const T*)dy,        \
                        (const T*)x, (const T*)residual, scale, shift, mean, invstd, partial, (int)N, (int)C, (int)HW, P)

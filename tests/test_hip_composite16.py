@@ -170,7 +170,11 @@ def test_composite_block_16bit_vs_oracle(ora, case, bstat):
         else:
             assert ran(bwd_table, "dw_wgrad_vec_kernel<%s, %d, true>" % (T, K)) == 1, bwd_table
         nstat = ran(bwd_table, "bn_bwd_coef_cp_kernel")
-        assert ran(bwd_table, "bn_bwd_reduce_kernel") == 3 - nstat and ran(bwd_table, "bn_bwd_apply_kernel") == 1
+        # BN3 (64 channels, no activation): the reduction + apply pair; with OFASR_BN_BWD_ONEPASS=1 (opt-in, measured slower in
+        # the step) a one-pass backward from registers when a channel fits a workgroup (N * HW <= 65536)
+        one3 = ran(bwd_table, "bn_bwd_onepass_kernel")
+        assert one3 == (1 if (N * Hh * Ww <= 65536 and os.environ.get("OFASR_BN_BWD_ONEPASS", "0") == "1") else 0), bwd_table
+        assert ran(bwd_table, "bn_bwd_reduce_kernel") == 3 - one3 - nstat and ran(bwd_table, "bn_bwd_apply_kernel") == 1 - one3
         # ... and no coefficient launch either: the consumers fold the reduction's partial slabs themselves (BwdXf::fold_*)
         assert ran(bwd_table, "bn_bwd_coef_kernel") == 0
         if K in (5, 7) and Ww in (32, 64):
@@ -179,7 +183,8 @@ def test_composite_block_16bit_vs_oracle(ora, case, bstat):
         else:
             assert ran(fwd_table, "dw_vec_kernel<%s, %d, false, true, true, false>" % (T, K)) == 1, fwd_table
             assert ran(bwd_table, "dw_vec_kernel<%s, %d, true, false, false, true>" % (T, K)) == 1, bwd_table
-    folded_bwd = ran(bwd_table, "bn_bwd_apply_kernel") == 1     # only BN3 has an apply pass
+    # only BN3 has an apply pass (or its one-pass form): BN1 / BN2 are folded into their consumers
+    folded_bwd = ran(bwd_table, "bn_bwd_apply_kernel") + ran(bwd_table, "bn_bwd_onepass_kernel") == 1
     dw_mma = ran(fwd_table, "dw_mfma_kernel") > 0
     assert ran(fwd_table, "bn_stats_kernel") == 0 and ran(fwd_table, "bn_finalize") == 0 or not (train and aligned)
 
