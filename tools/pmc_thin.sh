@@ -18,13 +18,13 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
     rocprofv3 --kernel-trace --pmc $grp -d "$R/$OUT/p$i" -o p --output-format csv -- python3 $R/tools/kbench.py --only "$ONLY" --dtype $DT --reps 6 > "$R/$OUT/p$i.log" 2>&1 || echo "pass $i failed" >> "$R/$OUT/fail.log"
 done
 python3 - "$R/$OUT" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, os, sys, collections
 out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "ct_" not in k:
+        if os.environ.get("KFILTER", "ct_") not in k:
             continue
         agg[k[:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fh:
