@@ -15,9 +15,10 @@
 // fp32) and, per kernel row ty, the weight slab [tx][16 k][64 m] (copied with 16-byte loads from an image laid out in
 // that order by conv_f32_prep_kernel): an A operand is one ds_read_b32 of 32 consecutive channels, a B operand one
 // ds_read_b32 of 32 consecutive pixels (both conflict-free), K*8*2 MFMAs per wave and (chunk, ty).
-// weight gradient: rows = co, columns = ci, reduction over pixels (2 per MFMA); a block of K waves owns a 32 x 32
-// (co, ci) tile and a range of 4 x 32 pixel tiles, wave ty keeps its K accumulators (tx) in registers over the whole
-// range; per-range partial slabs are summed in a fixed order (deterministic, no atomics).
+// weight gradient: rows = co, columns = ci, reduction over pixels (2 per MFMA); a block of 2 K compute waves + 2 loader
+// waves owns a 32 x 32 (co, ci) tile and a range of 4 x 32 pixel tiles; a compute wave keeps the K accumulators (tx) of
+// its kernel row in registers over the whole range, the loader waves fill the other LDS buffer meanwhile; per-range
+// partial slabs are summed in a fixed order (deterministic, no atomics).
 #include "ofasr_common.h"
 
 namespace ofasr {
@@ -27,10 +28,8 @@ typedef __attribute__((ext_vector_type(16))) float cf_f32x16;
 constexpr int CF_TH = 4, CF_TW = 32, CF_KC = 16, CF_MB = 64;
 constexpr int CF_WG_RB = 1;    // weight gradient: 32-row output-channel blocks per wave
 constexpr int CF_WG_TH = 4;    // weight gradient: rows of the pixel tile staged per barrier round
-// weight gradient: waves per kernel row.  A block of K = 5 waves puts two of them on one SIMD and one on each of the
-// others, so the matrix pipes of three SIMDs idle half the time (5/8 of the fp32 matrix rate at best, whatever the
-// number of blocks per CU -- every block maps its waves the same way).  With two waves per kernel row, each on half of
-// the tile's pixel pairs, a block is 10 waves = 3 + 3 + 2 + 2 (10/12); the two halves write separate partial slabs.
+// weight gradient: compute waves per kernel row (each kernel row's pixel pairs are shared by two waves, which write
+// separate partial slabs; see the wave shares at the kernel)
 constexpr int CF_WG_HALVES = 2;
 
 // weight image [kc][ty][tx][kk = 16][m = Mpad] fp32 (zeros beyond the slice)
@@ -121,137 +120,186 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(const float* __restrict__
     }
 }
 
-// ---- weight gradient: partial[split][co][ci][ty][tx] over the block's pixel tiles
+// ---- weight gradient: partial[split][half][co][ci][ty][tx] over the block's pixel tiles
+// A wave owns one kernel row ty (its K accumulators tx stay in registers over the block's whole pixel range) and a range
+// of the tile's 8 half rows (a half row = 8 pixel pairs = 8 x K MFMAs).  The hardware puts wave i of a block on SIMD
+// i % 4, so 2 K waves are 3 + 3 + 2 + 2 (K = 5) or 2 + 2 + 1 + 1 (K = 3) per SIMD: the shares below give every SIMD the
+// same number of half rows (10 of 40, 6 of 24) instead of every wave -- each kernel row is still covered by exactly two
+// waves, which write the two partial slabs `half` of their split.  entry = ty | hb << 4 | he << 8 | half << 12
+__constant__ const unsigned short cf_wg_shares5[10] = {0x1850, 0x1852, 0x0500, 0x0502, 0x1851, 0x1853, 0x0501, 0x0503, 0x0404, 0x1844};
+__constant__ const unsigned short cf_wg_shares3[6] = {0x1860, 0x1861, 0x0600, 0x0601, 0x0402, 0x1842};
+
 template <int KS>
-__global__ void __launch_bounds__(64 * KS * CF_WG_HALVES) conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ void __launch_bounds__(128 * KS + 128) conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                  float* __restrict__ part, int Cin, int Cout, int H, int W,
                                                                  int tiles_x, int tiles_y, int ntiles, int nsplit) {
-    constexpr int P = KS / 2, THREADS = 64 * KS * CF_WG_HALVES;
+    static_assert(CF_WG_RB == 1 && CF_WG_TH == 4 && CF_TW == 32 && CF_WG_HALVES == 2, "the wave shares assume 4 x 32 tiles");
+    constexpr int P = KS / 2, THREADS = 128 * KS + 128;   // 2 K compute waves + 2 loader waves
     constexpr int RH = CF_WG_TH + KS - 1, RW = CF_TW + KS - 1;
-    constexpr int GPL = CF_WG_TH * CF_TW + 1;                  // dY plane pitch: bank = (co + pixel) % 32 -> conflict-free A reads
-    constexpr int XPL = RH * RW + 1;
-    // output channels per block = CF_WG_RB 32-row MFMA blocks per wave (2 measured slower: 57 against 67 TFLOP/s on
-    // 64 -> 256 @128x128 -- 160 accumulator registers on top of the staging registers; 2-row pixel tiles, CF_WG_TH = 2,
-    // for twice the blocks per CU: 63)
-    constexpr int NRB = CF_WG_RB, NCO = 32 * NRB;
-    __shared__ float Gs[NCO * GPL];
-    __shared__ float Xs[32 * XPL];
+    // plane pitches = 2 * odd: the 32 channel lanes x 2 pixel lanes of an operand read fall on 64 different banks, and
+    // the staged pairs / quads stay 8-byte aligned (ds_write_b64)
+    constexpr int GPL = CF_WG_TH * CF_TW + 2, XPL = RH * RW + 2;
+    constexpr int GSZ = 32 * GPL, BUF = GSZ + 32 * XPL;
+    static_assert((RH * RW) % 4 == 0, "pitch parity");
+    extern __shared__ __attribute__((aligned(16))) char cf_wg_smem[];
+    float* lds = reinterpret_cast<float*>(cf_wg_smem);       // [2][BUF]: dY planes, then X planes (one buffer on the slow path)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ty = wv % KS, half = wv / KS;                    // this wave's kernel row and its share of the pixel pairs
+    const unsigned share = KS == 5 ? cf_wg_shares5[wv < 10 ? wv : 0] : cf_wg_shares3[wv < 6 ? wv : 0];
+    const int ty = share & 15, hb = (share >> 4) & 15, he = (share >> 8) & 15, half = share >> 12;
     const int c = lane & 31, kk = lane >> 5;
     // Block order: the (co, ci) groups of one pixel split read the same dY / X tiles, so they should run at the same time
     // on the same XCD (each XCD has its own L2; consecutive workgroup ids go round the 8 XCDs).  id = 8 * (G * q + group)
     // + xcd with split = 8 q + xcd: the G blocks of a split follow each other on one XCD and the tiles are fetched from
-    // HBM about once instead of once per group (measured 49 -> see DESIGN.md TFLOP/s on 64->256 @128x128).
-    const int gco = (Cout + NCO - 1) / NCO, G = gco * ((Cin + 31) / 32);
+    // HBM about once instead of once per group.
+    const int gco = (Cout + 31) / 32, G = gco * ((Cin + 31) / 32);
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int group = j % G, split = (j / G) * 8 + xcd;
     if (split >= nsplit) return;     // workgroup-uniform: the grid is padded to whole rounds of 8 splits
-    const int co0 = (group % gco) * NCO, ci0 = (group / gco) * 32;
+    const int co0 = (group % gco) * 32, ci0 = (group / gco) * 32;
     const long long plane = (long long)H * W;
-    cf_f32x16 acc[NRB][KS];
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-        for (int tx = 0; tx < KS; ++tx)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[rb][tx][i] = 0.f;
     const int t0 = (int)((long long)split * ntiles / nsplit), t1 = (int)((long long)(split + 1) * ntiles / nsplit);
-    auto compute = [&]() {
-        // pixel pair s = (row r, columns 2q, 2q+1); lane (c, kk): A = dY[co = c][pixel 2s + kk], B = X[ci = c][same pixel + tap]
-        constexpr int NS = CF_WG_TH * CF_TW / 2 / CF_WG_HALVES;
-#pragma unroll 2
-        for (int s = half * NS; s < (half + 1) * NS; ++s) {
-            const int p = 2 * s + kk, r = p / CF_TW, col = p % CF_TW;
-            float a[NRB];
+    // Fast staging (K = 5, W % 4 == 0, aligned bases): two extra LOADER waves (which the hardware puts on the two SIMDs
+    // that hold only two compute waves) bring the next tile's dY and X quads through registers into the OTHER LDS buffer
+    // while the compute waves have this tile in the matrix cores: the compute waves issue nothing but operand reads and
+    // MFMAs, the staging's address arithmetic runs beside them on the vector ALUs, one barrier per tile.
+    //   dY: thread = (plane co, tile row), its 8 quads along the row;   X: lane = (window row, channel % 8), its 10
+    //   aligned quads [w0 - 4, w0 + 36) of the row (the window is [w0 - 2, w0 + 34)) for 2 channel groups per wave.
+    // Every request is base (uniform: image, column quad) + one 32-bit lane offset (channel, clamped row): no per-request
+    // address arithmetic and no per-request selects (a value select after a load is compiled into a branch that waits for
+    // it, an address select into two loads in two branches).  Rows / channels outside the tensor are clamped and zeroed
+    // by a lane mask, column quads outside the tensor (uniform) read the tile's first quad and are zeroed likewise.
+    const bool fast = KS == 5 && (W % 4 == 0) && (long long)(Cin > Cout ? Cin : Cout) * plane < (1LL << 31) &&
+                      ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+    const bool loader = wv >= CF_WG_HALVES * KS;               // wave-uniform
+    if constexpr (KS == 5) {
+    if (fast && loader) {     // (no accumulators on this path: the staging registers have the file to themselves)
+        static_assert(KS != 5 || (RH == 8 && RW == 36), "loader lane mapping");
+        constexpr int XQ = 10, GQ = CF_TW / 4;
+        const int ltid = tid - CF_WG_HALVES * KS * 64, lw = ltid >> 6;
+        const int g_co = ltid >> 2, g_r = ltid & 3;
+        const bool g_ch_ok = co0 + g_co < Cout;
+        const unsigned g_ch_off = (unsigned)(g_ch_ok ? co0 + g_co : Cout - 1) * (unsigned)plane;
+        const int g_dst = g_co * GPL + g_r * CF_TW;
+        const int x_r = ltid & 7, x_cl = (ltid >> 3) & 7;
+        bool x_ch_ok[2];
+        unsigned x_ch_off[2];
+        int x_dst[2];
 #pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) a[rb] = Gs[(32 * rb + c) * GPL + p];
-            const float* xb = Xs + c * XPL + (r + ty) * RW + col;
+        for (int gi = 0; gi < 2; ++gi) {
+            const int ci = (2 * lw + gi) * 8 + x_cl;
+            x_ch_ok[gi] = ci0 + ci < Cin;
+            x_ch_off[gi] = (unsigned)(x_ch_ok[gi] ? ci0 + ci : Cin - 1) * (unsigned)plane;
+            x_dst[gi] = GSZ + ci * XPL + x_r * RW - 2;
+        }
+        auto stage = [&](int t, float* buf) {
+            const int n = t / (tiles_x * tiles_y), rem = t - n * (tiles_x * tiles_y);
+            const int h0 = (rem / tiles_x) * CF_WG_TH, w0 = (rem % tiles_x) * CF_TW;       // all uniform
+            const float* gimg = dy + (long long)n * Cout * plane;
+            const float* ximg = x + (long long)n * Cin * plane;
+            const int gh = h0 + g_r;
+            const unsigned g_off = g_ch_off + (unsigned)(gh < H ? gh : H - 1) * (unsigned)W;
+            const unsigned g_mask = g_ch_ok && gh < H ? ~0u : 0u;
+            const int xh = h0 - P + x_r, xhc = xh < 0 ? 0 : (xh < H ? xh : H - 1);
+            const bool x_row_ok = xh >= 0 && xh < H;
+            float4 gq[GQ], xq[2][XQ];
 #pragma unroll
-            for (int tx = 0; tx < KS; ++tx) {
-                const float b = xb[tx];
+            for (int jq = 0; jq < GQ; ++jq) {
+                const int gw = w0 + 4 * jq;
+                const float* col = gimg + (gw < W ? gw : w0);                       // uniform
+                gq[jq] = *reinterpret_cast<const float4*>(col + g_off);
+            }
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) acc[rb][tx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb], b, acc[rb][tx], 0, 0, 0);
+            for (int gi = 0; gi < 2; ++gi) {
+                const unsigned x_off = x_ch_off[gi] + (unsigned)xhc * (unsigned)W;
+#pragma unroll
+                for (int jq = 0; jq < XQ; ++jq) {
+                    const int gw = w0 - 4 + 4 * jq;
+                    const float* col = ximg + (gw >= 0 && gw < W ? gw : w0);        // uniform
+                    xq[gi][jq] = *reinterpret_cast<const float4*>(col + x_off);
+                }
+            }
+            auto masked = [](float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); };
+#pragma unroll
+            for (int jq = 0; jq < GQ; ++jq) {
+                const unsigned m = w0 + 4 * jq < W ? g_mask : 0u;
+                float2* d = reinterpret_cast<float2*>(buf + g_dst + 4 * jq);
+                d[0] = make_float2(masked(gq[jq].x, m), masked(gq[jq].y, m));
+                d[1] = make_float2(masked(gq[jq].z, m), masked(gq[jq].w, m));
+            }
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                const unsigned x_mask = x_ch_ok[gi] && x_row_ok ? ~0u : 0u;
+#pragma unroll
+                for (int jq = 0; jq < XQ; ++jq) {
+                    const int gw = w0 - 4 + 4 * jq;
+                    const unsigned m = gw >= 0 && gw < W ? x_mask : 0u;
+                    float* d = buf + x_dst[gi] + 4 * jq;                           // window columns 4 jq - 2 .. 4 jq + 1
+                    if (jq > 0) *reinterpret_cast<float2*>(d) = make_float2(masked(xq[gi][jq].x, m), masked(xq[gi][jq].y, m));
+                    if (jq < XQ - 1) *reinterpret_cast<float2*>(d + 2) = make_float2(masked(xq[gi][jq].z, m), masked(xq[gi][jq].w, m));
+                }
+            }
+        };
+        if (t0 < t1) stage(t0, lds);
+        __syncthreads();
+        for (int t = t0; t < t1; ++t) {
+            if (t + 1 < t1) stage(t + 1, lds + (((t - t0) & 1) ^ 1) * BUF);
+            __syncthreads();   // the compute waves are done with this tile's buffer, the other one is filled
+        }
+        return;
+    }
+    }
+    cf_f32x16 acc[KS];
+#pragma unroll
+    for (int tx = 0; tx < KS; ++tx)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tx][i] = 0.f;
+    // Half rows [h0, h1) of the tile in `buf`: pixel pair (half row hr, q) = row hr / 2, columns 16 (hr & 1) + 2 q + kk;
+    // lane (c, kk): A = dY[co = c][pixel], B = X[ci = c][pixel + tap].  The operands of pair q + 1 are requested before
+    // the K MFMAs of pair q are issued (two register sets), so the LDS latency is covered by the wave's own matrix work.
+    auto compute = [&](const float* buf, int h0, int h1) {
+        if (h0 >= h1) return;
+        const float* gl = buf + c * GPL + kk;
+        const float* xl = buf + GSZ + c * XPL + ty * RW + kk;
+        float a[2], b[2][KS];
+        auto request = [&](int hr, int q, int slot) {
+            a[slot] = gl[hr * 16 + 2 * q];
+            const float* xp = xl + (hr >> 1) * RW + (hr & 1) * 16 + 2 * q;
+#pragma unroll
+            for (int tx = 0; tx < KS; ++tx) b[slot][tx] = xp[tx];
+        };
+        request(h0, 0, 0);
+        for (int hr = h0; hr < h1; ++hr) {
+            const int hn = hr + 1 < h1 ? hr + 1 : hr;          // the last request past the range re-reads (unused)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (q < 7) request(hr, q + 1, (q + 1) & 1);
+                else request(hn, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tx = 0; tx < KS; ++tx)
+                    acc[tx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1], b[q & 1][tx], acc[tx], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
-    // Fast staging (even window start, W % 4 == 0, aligned bases): the tile's dY quads and X pairs are requested as
-    // straight-line vector loads from clamped addresses into registers -- all in flight together, and for tile t+1 while
-    // tile t is in the matrix cores -- and zeroed afterwards where they lie outside the tensor.  (Element-wise guarded
-    // loads in a loop cost one memory round trip each: the kernel then spends its time staging, 49 TFLOP/s.)
-    const bool fast = (P % 2 == 0) && (W % 4 == 0) &&
-                      ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
     if (fast) {
-        constexpr int NQG = NCO * CF_WG_TH * CF_TW / 4, NG = (NQG + THREADS - 1) / THREADS;
-        constexpr int XW2 = RW / 2, NQX = 32 * RH * XW2, NX = (NQX + THREADS - 1) / THREADS;
-        float4 g[NG];
-        float2 xv[NX];
-        auto load_tile = [&](int t) {
-            const int n = t / (tiles_x * tiles_y), rem = t - n * (tiles_x * tiles_y);
-            const int h0 = (rem / tiles_x) * CF_WG_TH, w0 = (rem % tiles_x) * CF_TW;
-#pragma unroll
-            for (int it = 0; it < NG; ++it) {
-                const int q0 = tid + it * THREADS, q = q0 < NQG ? q0 : NQG - 1;
-                const int co = q / (CF_WG_TH * CF_TW / 4), pq = q - co * (CF_WG_TH * CF_TW / 4);
-                const int gh = h0 + pq / (CF_TW / 4), gw = w0 + 4 * (pq % (CF_TW / 4));
-                const int coc = co0 + co < Cout ? co0 + co : Cout - 1, ghc = gh < H ? gh : H - 1, gwc = gw + 4 <= W ? gw : W - 4;
-                const float4 v = *reinterpret_cast<const float4*>(dy + ((long long)n * Cout + coc) * plane + (long long)ghc * W + gwc);
-                const bool ok = co0 + co < Cout && gh < H && gw < W;
-                g[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int it = 0; it < NX; ++it) {
-                const int q0 = tid + it * THREADS, q = q0 < NQX ? q0 : NQX - 1;
-                const int ci = q / (RH * XW2), r2 = q - ci * (RH * XW2);
-                const int r = r2 / XW2, c2 = r2 - r * XW2;
-                const int gh = h0 - P + r, gw = w0 - P + 2 * c2;
-                const int cic = ci0 + ci < Cin ? ci0 + ci : Cin - 1;
-                const int ghc = gh < 0 ? 0 : (gh < H ? gh : H - 1), gwc = gw < 0 ? 0 : (gw + 2 <= W ? gw : W - 2);
-                const float2 v = *reinterpret_cast<const float2*>(x + ((long long)n * Cin + cic) * plane + (long long)ghc * W + gwc);
-                const bool ok = ci0 + ci < Cin && gh >= 0 && gh < H && gw >= 0 && gw < W;
-                xv[it] = ok ? v : make_float2(0.f, 0.f);
-            }
-        };
-        auto store_tile = [&]() {
-#pragma unroll
-            for (int it = 0; it < NG; ++it) {
-                const int q = tid + it * THREADS;
-                if (q < NQG) {
-                    const int co = q / (CF_WG_TH * CF_TW / 4), pq = q - co * (CF_WG_TH * CF_TW / 4);
-                    float* d = Gs + co * GPL + 4 * pq;
-                    d[0] = g[it].x; d[1] = g[it].y; d[2] = g[it].z; d[3] = g[it].w;
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < NX; ++it) {
-                const int q = tid + it * THREADS;
-                if (q < NQX) {
-                    const int ci = q / (RH * XW2), r2 = q - ci * (RH * XW2);
-                    float* d = Xs + ci * XPL + 2 * r2;     // r * RW + 2 c2 = 2 (r * XW2 + c2)
-                    d[0] = xv[it].x; d[1] = xv[it].y;
-                }
-            }
-        };
-        if (t0 < t1) load_tile(t0);
+        __syncthreads();
         for (int t = t0; t < t1; ++t) {
+            compute(lds + ((t - t0) & 1) * BUF, hb, he);
             __syncthreads();
-            store_tile();
-            __syncthreads();
-            if (t + 1 < t1) load_tile(t + 1);
-            compute();
         }
     } else {
     for (int t = t0; t < t1; ++t) {
         const int n = t / (tiles_x * tiles_y), rem = t - n * (tiles_x * tiles_y);
         const int h0 = (rem / tiles_x) * CF_WG_TH, w0 = (rem % tiles_x) * CF_TW;
         __syncthreads();
-        for (int e = tid; e < NCO * CF_WG_TH * CF_TW; e += THREADS) {
+        for (int e = tid; e < 32 * CF_WG_TH * CF_TW; e += THREADS) {
             const int co = e / (CF_WG_TH * CF_TW), p = e - co * (CF_WG_TH * CF_TW);
             const int gh = h0 + p / CF_TW, gw = w0 + p % CF_TW;
             float v = 0.f;
             if (co0 + co < Cout && gh < H && gw < W) v = dy[((long long)n * Cout + co0 + co) * plane + (long long)gh * W + gw];
-            Gs[co * GPL + p] = v;
+            lds[co * GPL + p] = v;
         }
         for (int e = tid; e < 32 * RH * RW; e += THREADS) {
             const int ci = e / (RH * RW), r = (e - ci * (RH * RW)) / RW, col = e - ci * (RH * RW) - r * RW;
@@ -259,32 +307,40 @@ __global__ void __launch_bounds__(64 * KS * CF_WG_HALVES) conv_f32_wgrad_kernel(
             float v = 0.f;
             if (ci0 + ci < Cin && gh >= 0 && gh < H && gw >= 0 && gw < W)
                 v = x[((long long)n * Cin + ci0 + ci) * plane + (long long)gh * W + gw];
-            Xs[ci * XPL + r * RW + col] = v;
+            lds[GSZ + ci * XPL + r * RW + col] = v;
         }
         __syncthreads();
-        compute();
+        if (!loader) compute(lds, hb, he);
     }
     }
-    // D[row = co][col = ci]
+    if (loader) return;
+    // D[row = co][col = ci]: slab [tap][co][ci] -- the 32 ci lanes of a row are one 128-byte segment (the tensor's own
+    // order [co][ci][tap] would make every store 64 scattered words); conv_f32_wgrad_reduce_kernel transposes
     float* dst = part + ((long long)split * CF_WG_HALVES + half) * Cout * Cin * KS * KS;
     const int ci = ci0 + c;
     if (ci < Cin) {
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
+        for (int tx = 0; tx < KS; ++tx)
 #pragma unroll
-            for (int tx = 0; tx < KS; ++tx)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int co = co0 + 32 * rb + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
-                    if (co < Cout) dst[(((long long)co * Cin + ci) * KS + ty) * KS + tx] = acc[rb][tx][reg];
-                }
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = co0 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+                if (co < Cout) dst[((long long)(ty * KS + tx) * Cout + co) * Cin + ci] = acc[tx][reg];
+            }
     }
 }
 
-// 16 outputs x 16 slab lanes per block: lane z adds the slabs z, z + 16, ... in that order (8 requests in flight), the 16
-// lanes are then added in lane order: a fixed order, so the result is deterministic
+// LDS bytes of the weight-gradient kernel: two tile buffers where the fast staging can apply (even padding)
+static size_t cf_wg_lds_bytes(int K) {
+    const int RH = CF_WG_TH + K - 1, RW = CF_TW + K - 1;
+    const size_t buf = (size_t)32 * (CF_WG_TH * CF_TW + 2) + (size_t)32 * (RH * RW + 2);
+    return ((K / 2) % 2 == 0 ? 2 : 1) * buf * sizeof(float);
+}
+
+// 16 slab elements x 16 slab lanes per block: lane z adds the slabs z, z + 16, ... in that order (8 requests in flight),
+// the 16 lanes are then added in lane order: a fixed order, so the result is deterministic.  Slab order [tap][co][ci]
+// -> tensor order [co][ci][tap]
 __global__ void __launch_bounds__(256) conv_f32_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                    long long total, int nslabs) {
+                                                                    long long total, int nslabs, int CC, int KK) {
     __shared__ float red[256];
     const int el = threadIdx.x & 15, zl = threadIdx.x >> 4;
     const long long idx = (long long)blockIdx.x * 16 + el;
@@ -306,7 +362,8 @@ __global__ void __launch_bounds__(256) conv_f32_wgrad_reduce_kernel(const float*
         float t = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) t += red[16 * j + el];
-        dw[idx] = t;
+        const int tap = (int)(idx / CC), cc = (int)(idx - (long long)tap * CC);
+        dw[(long long)cc * KK + tap] = t;
     }
 }
 
@@ -314,7 +371,10 @@ static int cf_mpad(int64_t M) { return (int)(cdiv(M, CF_MB) * CF_MB); }
 static int cf_nsplit(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W) {
     const int64_t ntiles = N * cdiv(H, CF_WG_TH) * cdiv(W, CF_TW);
     const int64_t groups = cdiv(Cout, 32 * CF_WG_RB) * cdiv(Cin, 32);
-    int64_t want = 1024 / (groups > 0 ? groups : 1);   // ~4 blocks per CU
+    // one block per CU, one round: each block pays its prologue (first tile's staging, exposed) and its partial slab
+    // once (512 blocks: -1 %, 1024: -4 % on 64 -> 256 @128, -13 % @64)
+    static const int blocks = [] { const char* e = getenv("OFASR_CONV_F32_WG_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    int64_t want = blocks / (groups > 0 ? groups : 1);
     if (want > ntiles) want = ntiles;
     if (want < 1) want = 1;
     return (int)want;
@@ -413,16 +473,21 @@ OFASR_EXPORT int ofasr_conv2d_f32_wgrad(const void* dy, const void* x, float* dw
     dim3 grid((unsigned)nblocks);
     prof_note(4.0 * (double)N * (double)H * (double)W * (double)(Cin + Cout),
               2.0 * (double)N * (double)H * (double)W * (double)Cin * (double)Cout * K * K);
-    if (K == 5)
-        OFASR_LAUNCH(conv_f32_wgrad_kernel<5>, grid, dim3(64 * 5 * CF_WG_HALVES), 0, st, (const float*)dy, (const float*)x, (float*)workspace,
+    const size_t lds = cf_wg_lds_bytes(K);
+    if (K == 5) {
+        static const bool attr5 = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32_wgrad_kernel<5>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)cf_wg_lds_bytes(5)), true);
+        (void)attr5;
+        OFASR_LAUNCH(conv_f32_wgrad_kernel<5>, grid, dim3(64 * 5 * CF_WG_HALVES + 128), lds, st, (const float*)dy, (const float*)x, (float*)workspace,
                      (int)Cin, (int)Cout, (int)H, (int)W, tiles_x, tiles_y, ntiles, nsplit);
-    else
-        OFASR_LAUNCH(conv_f32_wgrad_kernel<3>, grid, dim3(64 * 3 * CF_WG_HALVES), 0, st, (const float*)dy, (const float*)x, (float*)workspace,
+    } else {
+        OFASR_LAUNCH(conv_f32_wgrad_kernel<3>, grid, dim3(64 * 3 * CF_WG_HALVES + 128), lds, st, (const float*)dy, (const float*)x, (float*)workspace,
                      (int)Cin, (int)Cout, (int)H, (int)W, tiles_x, tiles_y, ntiles, nsplit);
+    }
     int rc = check_launch(name);
     if (rc) return rc;
     const long long total = (long long)Cout * Cin * K * K;
     OFASR_LAUNCH(conv_f32_wgrad_reduce_kernel, dim3((unsigned)cdiv(total, 16)), dim3(256), 0, st, (const float*)workspace, dw,
-                 total, nsplit * CF_WG_HALVES);
+                 total, nsplit * CF_WG_HALVES, (int)(Cout * Cin), K * K);
     return check_launch(name);
 }

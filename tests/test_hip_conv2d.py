@@ -145,7 +145,10 @@ def test_conv2d_ragged_width_vs_oracle(ora, case):
 
 @pytest.mark.parametrize("case", CASES + [(1, 64, 3, 6, 4, 3),     # X4 encoder tail at 6 x 4: narrower than a wide fragment of the thin weight gradient
                                           (1, 64, 64, 9, 125, 5), (2, 3, 64, 7, 62, 5), (1, 16, 16, 5, 13, 3),
-                                          (2, 64, 256, 16, 16, 5), (1, 40, 70, 6, 33, 3)])
+                                          (2, 64, 256, 16, 16, 5), (1, 40, 70, 6, 33, 3),
+                                          # weight gradient with loader waves (K = 5, W % 4 == 0): ragged channels, a 4-column
+                                          # second tile and a 2-row last tile; then 1 or 2 tiles per block (both LDS buffers)
+                                          (1, 40, 70, 6, 36, 5), (3, 64, 64, 64, 64, 5)])
 def test_conv2d_fp32_vs_oracle(ora, case):
     """fp32 activations (the reference's arithmetic) on the fp32 matrix instruction (csrc/conv2d_f32.hip): forward,
     input and weight gradients against the oracle conv (double accumulation) at fp32 tolerances, any width; the layer
