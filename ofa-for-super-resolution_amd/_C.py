@@ -15,7 +15,7 @@ import subprocess
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libofasr_hip.so")
+LIB_PATH = os.environ.get("OFASR_LIB_PATH") or os.path.join(_HERE, "csrc", "libofasr_hip.so")   # override: A/B of two builds on one box
 
 F32, F16, BF16 = 0, 1, 2
 

@@ -636,12 +636,17 @@ __global__ void __launch_bounds__(BN_THREADS) bn_bwd_reduce_ps_kernel(const uint
     for (int n = p; n < N; n += P) {
         for (int it = threadIdx.x; it < items; it += BN_THREADS) {
             const int h = it / Wq, wq = it - h * Wq;
-            uint4 dz[4];
+            uint4 dz[4], xv[4];
             bnps_load(dout, (long long)n * G + g, h, wq, H, Wq, dz);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[j] = x[((long long)n * C + 4 * g + j) * plane + it];
+            // all 8 requests of the item before the first use: with the x load inside the channel loop the compiler issued
+            // x[1..3] one at a time, each behind s_waitcnt vmcnt(0) -- 4 serial round trips per item, 0.98 TB/s
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float f[8], gd[8];
-                unpack16<T>(x[((long long)n * C + 4 * g + j) * plane + it], f);
+                unpack16<T>(xv[j], f);
                 unpack16<T>(dz[j], gd);
                 float s8 = 0.f, q8 = 0.f;
 #pragma unroll
@@ -698,13 +703,16 @@ __global__ void __launch_bounds__(BN_THREADS) bn_bwd_apply_ps_kernel(const uint4
     for (int n = p; n < N; n += P) {
         for (int it = threadIdx.x; it < items; it += BN_THREADS) {
             const int h = it / Wq, wq = it - h * Wq;
-            uint4 dz[4];
+            uint4 dz[4], xv[4];
             bnps_load(dout, (long long)n * G + g, h, wq, H, Wq, dz);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[j] = x[((long long)n * C + 4 * g + j) * plane + it];
+            __builtin_amdgcn_sched_barrier(0);   // all 8 requests of the item before the first use (as the reduction pass)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const long long off = ((long long)n * C + 4 * g + j) * plane + it;
                 float f[8], gd[8], o[8];
-                unpack16<T>(x[off], f);
+                unpack16<T>(xv[j], f);
                 unpack16<T>(dz[j], gd);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = k1[j] * (gd[e] - ka[j] - (f[e] - mu[j]) * is[j] * kb[j]);

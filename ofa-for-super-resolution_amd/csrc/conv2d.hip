@@ -444,7 +444,16 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const T* __restrict_
     __shared__ __attribute__((aligned(16))) char Yt[ROWS * 256];
     __shared__ __attribute__((aligned(16))) char Xt[2 * XW * REC];
 
-    const int split = blockIdx.x, ty = blockIdx.y, z = blockIdx.z;
+    // Block order: the K * nz blocks of one pixel split (kernel rows x channel slabs) read the same dY tiles and
+    // overlapping X windows, so they should run at the same time on the same XCD (each XCD has its own L2; consecutive
+    // workgroup ids go round the 8 XCDs): id = 8 * (G * q + group) + xcd with split = 8 q + xcd.  (With the split as
+    // the fastest grid index the 10 blocks of a split sat on different XCDs and every one fetched its tiles from HBM:
+    // 827 MB per launch for 168 MB of activations on 64 -> 256 @128x128.)
+    const int G = KS * P.nz;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int group = jb % G, split = (jb / G) * 8 + xcd;
+    if (split >= P.ksplit) return;     // workgroup-uniform: the grid is padded to whole rounds of 8 splits
+    const int ty = group % KS, z = group / KS;
     const int coslab = z / P.ncislab, cislab = z % P.ncislab;
     const int tid = threadIdx.x, lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -494,11 +503,20 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const T* __restrict_
             const int gy = ty0 + r + ty - PAD, gx = tx0 - 8 + 8 * run;
             const bool inb = gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
             const int cbase = cislab * CIB + 8 * cg;
+            // branch-free: a run outside the tensor reads the image's first run instead and is masked to zero afterwards (a
+            // load under a lane-dependent condition ends its basic block with s_waitcnt vmcnt(0): the 8 requests of a task
+            // were 8 serial round trips, as were the 4 of a dY thread below -- 12 per tile, 32 % of the matrix rate)
             uint4 v[8];
+            uint32_t okm[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                v[i] = make_uint4(0, 0, 0, 0);
-                if (inb && cbase + i < P.Cin) v[i] = *reinterpret_cast<const uint4*>(xn + ((long long)(cbase + i) * P.H + gy) * P.W + gx);
+                const bool ok = inb && cbase + i < P.Cin;
+                okm[i] = ok ? 0xffffffffu : 0u;
+                v[i] = *reinterpret_cast<const uint4*>(xn + (ok ? ((long long)(cbase + i) * P.H + gy) * P.W + gx : 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i].x &= okm[i]; v[i].y &= okm[i]; v[i].z &= okm[i]; v[i].w &= okm[i];
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -521,19 +539,21 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const T* __restrict_
 #pragma unroll
         for (int i0 = 0; i0 < NYT; i0 += 4 * 256) {
             uint4 v[4];
+            uint32_t okm[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int idx = i0 + j * 256 + tid;
                 const int chunk = idx & 15, row = idx >> 4;
                 const int co = coslab * ROWS + row, gy = ty0 + (chunk >> 3), gx = tx0 + 8 * (chunk & 7);
-                v[j] = make_uint4(0, 0, 0, 0);
-                if (idx < NYT && co < P.Cout && gy < P.H && gx < P.W)
-                    v[j] = *reinterpret_cast<const uint4*>(dyn + ((long long)co * P.H + gy) * P.W + gx);
+                const bool ok = idx < NYT && co < P.Cout && gy < P.H && gx < P.W;
+                okm[j] = ok ? 0xffffffffu : 0u;
+                v[j] = *reinterpret_cast<const uint4*>(dyn + (ok ? ((long long)co * P.H + gy) * P.W + gx : 0));
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int idx = i0 + j * 256 + tid;
                 const int chunk = idx & 15, row = idx >> 4;
+                v[j].x &= okm[j]; v[j].y &= okm[j]; v[j].z &= okm[j]; v[j].w &= okm[j];
                 if (idx < NYT) *reinterpret_cast<uint4*>(Yt + row * 256 + ((chunk ^ (row & 15)) << 4)) = v[j];
             }
         }
@@ -661,6 +681,7 @@ static CvWgPlan cv_wg_plan(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int6
     // two blocks per CU, but at least 8 pixel tiles per block (every split costs a 40 KB slab per wave)
     int ks = 512 / (K * P.nz);
     ks = ks > P.ntiles / 8 ? P.ntiles / 8 : ks;
+    if (ks > 8) ks -= ks % 8;     // whole rounds of the 8 XCDs
     P.ksplit = ks < 1 ? 1 : ks;
     const int nwq = wide ? (rcls == 0 ? 4 : 2) : (rcls == 0 ? 2 : 1);   // (wco, wci) pairs per block
     p.part_bytes = (size_t)P.ksplit * K * P.nz * nwq * (p.rbw * K * 16 * 64) * sizeof(float);
@@ -671,7 +692,7 @@ template <typename T>
 static int launch_conv2d_wgrad(const char* name, const void* dy, const void* x, float* dw, int K, const CvWgPlan& p, void* ws,
                                hipStream_t st) {
     const CvWgParams& P = p.P;
-    dim3 grid((unsigned)P.ksplit, (unsigned)K, (unsigned)P.nz);
+    dim3 grid((unsigned)(cdiv(P.ksplit, 8) * 8 * K * P.nz));
     prof_note(p.note_bytes, p.note_flops);
 #define OFASR_WG(KS, RBW, WCO, WCI, WK)                                                                              \
     {                                                                                                                \

@@ -336,32 +336,30 @@ static size_t cf_wg_lds_bytes(int K) {
     return ((K / 2) % 2 == 0 ? 2 : 1) * buf * sizeof(float);
 }
 
-// 16 slab elements x 16 slab lanes per block: lane z adds the slabs z, z + 16, ... in that order (8 requests in flight),
-// the 16 lanes are then added in lane order: a fixed order, so the result is deterministic.  Slab order [tap][co][ci]
-// -> tensor order [co][ci][tap]
+// 64 slab elements x 4 slab lanes per block: lane z adds the slabs z, z + 4, ... in that order (8 requests in flight, 256-byte
+// segments), the 4 lanes are then added in lane order: a fixed order, so the result is deterministic.  Slab order
+// [tap][co][ci] -> tensor order [co][ci][tap]
 __global__ void __launch_bounds__(256) conv_f32_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                     long long total, int nslabs, int CC, int KK) {
     __shared__ float red[256];
-    const int el = threadIdx.x & 15, zl = threadIdx.x >> 4;
-    const long long idx = (long long)blockIdx.x * 16 + el;
+    const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * 64 + el;
     const long long idc = idx < total ? idx : total - 1;
     float s = 0.f;
-    for (int z0 = zl; z0 < nslabs; z0 += 16 * 8) {
+    for (int z0 = zl; z0 < nslabs; z0 += 4 * 8) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int z = z0 + 16 * j < nslabs ? z0 + 16 * j : nslabs - 1;
+            const int z = z0 + 4 * j < nslabs ? z0 + 4 * j : nslabs - 1;
             v[j] = part[(long long)z * total + idc];
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += z0 + 16 * j < nslabs ? v[j] : 0.f;
+        for (int j = 0; j < 8; ++j) s += z0 + 4 * j < nslabs ? v[j] : 0.f;
     }
     red[threadIdx.x] = s;
     __syncthreads();
     if (zl == 0 && idx < total) {
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) t += red[16 * j + el];
+        const float t = ((red[el] + red[64 + el]) + red[128 + el]) + red[192 + el];
         const int tap = (int)(idx / CC), cc = (int)(idx - (long long)tap * CC);
         dw[(long long)cc * KK + tap] = t;
     }
@@ -487,7 +485,7 @@ OFASR_EXPORT int ofasr_conv2d_f32_wgrad(const void* dy, const void* x, float* dw
     int rc = check_launch(name);
     if (rc) return rc;
     const long long total = (long long)Cout * Cin * K * K;
-    OFASR_LAUNCH(conv_f32_wgrad_reduce_kernel, dim3((unsigned)cdiv(total, 16)), dim3(256), 0, st, (const float*)workspace, dw,
+    OFASR_LAUNCH(conv_f32_wgrad_reduce_kernel, dim3((unsigned)cdiv(total, 64)), dim3(256), 0, st, (const float*)workspace, dw,
                  total, nsplit * CF_WG_HALVES, (int)(Cout * Cin), K * K);
     return check_launch(name);
 }
