@@ -115,6 +115,46 @@ __device__ __forceinline__ void stage_w_tile(char* Wt, const WView& wv, int m0, 
     } else {
         constexpr int NIT = ROWS * 16 / PW_THREADS;  // float4 chunks per thread
         float4 v[NIT];
+        // slices whose chunks are wholly inside or outside (K % 4 == 0 row-major, M % 4 == 0 transposed; uniform): all
+        // requests issued branch-free -- an outside chunk reads the slice's first chunk and is zeroed -- because a load
+        // under its bounds test ends the basic block with s_waitcnt vmcnt(0): NIT serial L2 round trips per tile
+        if (wv.sk == 1 ? (wv.K % 4 == 0) : (wv.M % 4 == 0)) {
+            bool okv[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int q = tid + it * PW_THREADS;
+                long long off;
+                if (wv.sk == 1) {
+                    const int r = q >> 4, k = 4 * (q & 15);
+                    okv[it] = m0 + r < wv.M && k0 + k < wv.K;
+                    off = (long long)(m0 + r) * wv.sm + k0 + k;
+                } else {
+                    const int k = q / (ROWS / 4), r = 4 * (q - k * (ROWS / 4));
+                    okv[it] = k0 + k < wv.K && m0 + r < wv.M;
+                    off = (long long)(k0 + k) * wv.sk + m0 + r;
+                }
+                v[it] = *reinterpret_cast<const float4*>(wv.w + (okv[it] ? off : 0));
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int q = tid + it * PW_THREADS;
+                const float4 t = okv[it] ? v[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (wv.sk == 1) {
+                    const int r = q >> 4, k = 4 * (q & 15);
+                    if constexpr (Elem<T>::is16)
+                        *reinterpret_cast<uint2*>(Wt + wtile_off<T>(r, k)) = make_uint2(pack2<T>(t.x, t.y), pack2<T>(t.z, t.w));
+                    else
+                        *reinterpret_cast<float4*>(Wt + wtile_off<T>(r, k)) = t;
+                } else {
+                    const int k = q / (ROWS / 4), r = 4 * (q - k * (ROWS / 4));
+                    lds_store_w<T>(Wt, wtile_off<T>(r, k), t.x);
+                    lds_store_w<T>(Wt, wtile_off<T>(r + 1, k), t.y);
+                    lds_store_w<T>(Wt, wtile_off<T>(r + 2, k), t.z);
+                    lds_store_w<T>(Wt, wtile_off<T>(r + 3, k), t.w);
+                }
+            }
+            return;
+        }
         if (wv.sk == 1) {  // row-major slice: chunk = 4 consecutive k of one row
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -230,17 +270,28 @@ __device__ __forceinline__ void stage_x_tile(char* Xs, const T* __restrict__ xn,
     const int tid = threadIdx.x;
     if constexpr (Elem<T>::is16) {
         if (ALIGNED) {
-            // 64 rows x 16 chunks of 8 pixels (16 B); HW % 8 == 0 so a chunk is all-in or all-out
+            // 64 rows x 16 chunks of 8 pixels (16 B); HW % 8 == 0 so a chunk is all-in or all-out.  All four requests are
+            // issued before the first use, branch-free (a chunk outside the tensor reads the image's first chunk and is
+            // zeroed below): a load under its bounds test ends the basic block with s_waitcnt vmcnt(0) -- one round trip
+            // per request
+            uint4 vv[4];
+            bool okv[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int q = tid + it * PW_THREADS;
                 const int k = q >> 4, m = q & 15;
                 const int px = p0 + 8 * m;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (k0 + k < K && px < HW) {
-                    v = *reinterpret_cast<const uint4*>(xn + (long long)(k0 + k) * HW + px);
-                    if constexpr (XF) v = xf_apply8<T>(v, xf, k0 + k);
-                }
+                okv[it] = k0 + k < K && px < HW;
+                vv[it] = *reinterpret_cast<const uint4*>(xn + (okv[it] ? (long long)(k0 + k) * HW + px : 0));
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int q = tid + it * PW_THREADS;
+                const int k = q >> 4, m = q & 15;
+                uint4 v = vv[it];
+                if constexpr (XF) v = xf_apply8<T>(v, xf, k0 + k < K ? k0 + k : K - 1);
+                const uint32_t msk = okv[it] ? 0xffffffffu : 0u;
+                v = make_uint4(v.x & msk, v.y & msk, v.z & msk, v.w & msk);
                 char* row = Xs + k * XROW16;
                 if (PX == 4) {
                     // pixel 8m+i -> position 32*(i&3) + 2m + (i>>2): pairs (i, i+4) are adjacent
@@ -269,15 +320,23 @@ __device__ __forceinline__ void stage_x_tile(char* Xs, const T* __restrict__ xn,
         }
     } else {
         if (ALIGNED) {
-            // 64 rows x 32 chunks of 4 pixels (16 B); HW % 4 == 0
+            // 64 rows x 32 chunks of 4 pixels (16 B); HW % 4 == 0; the eight requests together, branch-free (as above)
+            uint4 vv[8];
+            bool okv[8];
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int q = tid + it * PW_THREADS;
                 const int k = q >> 5, m = q & 31;
                 const int px = p0 + 4 * m;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (k0 + k < K && px < HW) v = *reinterpret_cast<const uint4*>(xn + (long long)(k0 + k) * HW + px);
-                *reinterpret_cast<uint4*>(Xs + k * XROW32 + m * 16) = v;
+                okv[it] = k0 + k < K && px < HW;
+                vv[it] = *reinterpret_cast<const uint4*>(xn + (okv[it] ? (long long)(k0 + k) * HW + px : 0));
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int q = tid + it * PW_THREADS;
+                const int k = q >> 5, m = q & 31;
+                const uint32_t msk = okv[it] ? 0xffffffffu : 0u;
+                *reinterpret_cast<uint4*>(Xs + k * XROW32 + m * 16) = make_uint4(vv[it].x & msk, vv[it].y & msk, vv[it].z & msk, vv[it].w & msk);
             }
         } else {
             for (int e = tid; e < 64 * PW_TILE; e += PW_THREADS) {
@@ -792,6 +851,50 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_kernel(const T* __restric
             }
         }
     }
+    // a wave whose 32 rows x 64 pixels lie inside the tensor reads the addend and writes its rows as straight-line code
+    // (as pw_fanin_pipe_kernel: under the row test every addend load is its own round trip, 16 in a row)
+    if (ALIGNED && 32 * cb + 32 <= mloc && p0 + PW_TILE <= HW && !(addend && so.partial)) {
+        const int px = p0 + 64 * hh + 2 * c;
+        T* yw = yn + (long long)(32 * cb) * HW + px;
+        if constexpr (Elem<T>::is16) {
+            if (addend) {
+                const T* aw = addend + ((long long)n * wv.M + m_base + 32 * cb) * HW + px;
+                uint32_t ar[16];
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    ar[reg] = *reinterpret_cast<const uint32_t*>(aw + (long long)acc_row(reg, h) * HW);
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    T lo, hi;
+                    lo.v = (uint16_t)(ar[reg] & 0xffffu);
+                    hi.v = (uint16_t)(ar[reg] >> 16);
+                    acc[0][reg] += to_float(lo);
+                    acc[1][reg] += to_float(hi);
+                }
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                *reinterpret_cast<uint32_t*>(yw + (long long)acc_row(reg, h) * HW) = pack2<T>(acc[0][reg], acc[1][reg]);
+        } else {
+            if (addend) {
+                const T* aw = addend + ((long long)n * wv.M + m_base + 32 * cb) * HW + px;
+                float2 ar[16];
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    ar[reg] = *reinterpret_cast<const float2*>(aw + (long long)acc_row(reg, h) * HW);
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    acc[0][reg] += ar[reg].x;
+                    acc[1][reg] += ar[reg].y;
+                }
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                *reinterpret_cast<float2*>(yw + (long long)acc_row(reg, h) * HW) = make_float2(acc[0][reg], acc[1][reg]);
+        }
+        if (so.partial) stat_epilogue<T, 2>(acc, px, HW, c, h, 32 * cb, mloc, m_base, so, 2 * tile + hh);
+        return;
+    }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int r = 32 * cb + acc_row(reg, h);
@@ -1152,6 +1255,44 @@ __device__ __forceinline__ void stage_rows64(char* Lt, const T* __restrict__ bas
 // 8 KiB), so it only runs at HBM speed if every barrier interval moves a lot of data.
 template <typename T> struct WgStage { static constexpr int SUB = Elem<T>::is16 ? 4 : 2; };
 
+// The aligned staging in two halves: rows64_request issues the [64 rows][64 px] sub-tile's 16-byte requests branch-free
+// (a chunk outside the tensor reads the image's first chunk instead and is zeroed on deposit); rows64_deposit writes
+// them to the operand tile.  With the load under its bounds test -- stage_rows64 -- every request ended its basic block
+// with s_waitcnt vmcnt(0): the 16 requests of a stage were 16 serial round trips (fp32 expand gradient: 120 us for
+// 118 MB).
+template <typename T> struct Rows64 {
+    static constexpr int NIT = Elem<T>::is16 ? 2 : 4;     // 16-byte chunks per thread
+    static constexpr int CPR = Elem<T>::is16 ? 8 : 16;    // chunks per row
+    static constexpr int EPC = Elem<T>::is16 ? 8 : 4;     // elements per chunk
+    uint4 v[NIT];
+    uint32_t ok;
+};
+template <typename T>
+__device__ __forceinline__ void rows64_request(Rows64<T>& g, const T* __restrict__ base, int rows_total, int r0, int HW, int p0) {
+    const int tid = threadIdx.x;
+    g.ok = 0;
+#pragma unroll
+    for (int it = 0; it < Rows64<T>::NIT; ++it) {
+        const int q = tid + it * PW_THREADS;
+        const int r = q / Rows64<T>::CPR, ch = q % Rows64<T>::CPR;
+        const int px = p0 + Rows64<T>::EPC * ch;
+        const bool ok = r0 + r < rows_total && px < HW;
+        g.v[it] = *reinterpret_cast<const uint4*>(base + (ok ? (long long)(r0 + r) * HW + px : 0));
+        g.ok |= (ok ? 1u : 0u) << it;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void rows64_deposit(char* Lt, const Rows64<T>& g) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < Rows64<T>::NIT; ++it) {
+        const int q = tid + it * PW_THREADS;
+        const int r = q / Rows64<T>::CPR, ch = q % Rows64<T>::CPR;
+        const uint32_t m = (g.ok >> it) & 1u ? 0xffffffffu : 0u;
+        *reinterpret_cast<uint4*>(Lt + wtile_chunk_off<T>(r, ch)) = make_uint4(g.v[it].x & m, g.v[it].y & m, g.v[it].z & m, g.v[it].w & m);
+    }
+}
+
 template <typename T, bool ALIGNED>
 __global__ void __launch_bounds__(PW_THREADS) pw_wgrad_kernel(const T* __restrict__ R, const T* __restrict__ S,
                                                               float* __restrict__ part, int MR, int NS, int HW,
@@ -1169,16 +1310,7 @@ __global__ void __launch_bounds__(PW_THREADS) pw_wgrad_kernel(const T* __restric
     f32x16 acc = zero16();
     const int q_lo = z * stages_per_split;
     const int q_hi = min(total_stages, q_lo + stages_per_split);
-    for (int q = q_lo; q < q_hi; ++q) {
-        const int n = q / stages_per_img;
-        const int p0 = (q - n * stages_per_img) * (64 * SUB);
-        if (q > q_lo) __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < SUB; ++sub) {
-            stage_rows64<T, ALIGNED>(Rt + sub * TB, R + (long long)n * MR * HW, MR, r0, HW, p0 + 64 * sub);
-            stage_rows64<T, ALIGNED>(St + sub * TB, S + (long long)n * NS * HW, NS, s0, HW, p0 + 64 * sub);
-        }
-        __syncthreads();
+    auto multiply = [&]() {
 #pragma unroll
         for (int sub = 0; sub < SUB; ++sub) {
             const char* Rs = Rt + sub * TB;
@@ -1201,6 +1333,45 @@ __global__ void __launch_bounds__(PW_THREADS) pw_wgrad_kernel(const T* __restric
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
                 }
             }
+        }
+    };
+    if constexpr (ALIGNED) {
+        // stage q + 1 is requested into registers (64 of them) before stage q is multiplied: its round trip runs
+        // under the MFMAs and the barrier instead of after them
+        Rows64<T> rg[SUB], sg[SUB];
+        auto request = [&](int q) {
+            const int n = q / stages_per_img;
+            const int p0 = (q - n * stages_per_img) * (64 * SUB);
+#pragma unroll
+            for (int sub = 0; sub < SUB; ++sub) {
+                rows64_request<T>(rg[sub], R + (long long)n * MR * HW, MR, r0, HW, p0 + 64 * sub);
+                rows64_request<T>(sg[sub], S + (long long)n * NS * HW, NS, s0, HW, p0 + 64 * sub);
+            }
+        };
+        if (q_lo < q_hi) request(q_lo);
+        for (int q = q_lo; q < q_hi; ++q) {
+            if (q > q_lo) __syncthreads();
+#pragma unroll
+            for (int sub = 0; sub < SUB; ++sub) {
+                rows64_deposit<T>(Rt + sub * TB, rg[sub]);
+                rows64_deposit<T>(St + sub * TB, sg[sub]);
+            }
+            __syncthreads();
+            if (q + 1 < q_hi) request(q + 1);
+            multiply();
+        }
+    } else {
+        for (int q = q_lo; q < q_hi; ++q) {
+            const int n = q / stages_per_img;
+            const int p0 = (q - n * stages_per_img) * (64 * SUB);
+            if (q > q_lo) __syncthreads();
+#pragma unroll
+            for (int sub = 0; sub < SUB; ++sub) {
+                stage_rows64<T, ALIGNED>(Rt + sub * TB, R + (long long)n * MR * HW, MR, r0, HW, p0 + 64 * sub);
+                stage_rows64<T, ALIGNED>(St + sub * TB, S + (long long)n * NS * HW, NS, s0, HW, p0 + 64 * sub);
+            }
+            __syncthreads();
+            multiply();
         }
     }
     // D[row = R row][col = S row]: lane holds column c, 16 rows
