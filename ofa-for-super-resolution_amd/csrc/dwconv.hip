@@ -458,18 +458,16 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_mfma_kernel(const T* __restr
         const long long plane = (long long)(n0 + pl) * C + c;
         const uint4* src = reinterpret_cast<const uint4*>(x + plane * (long long)H * W);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int idx = lane + 64 * it;
-            nxt[it] = make_uint4(0, 0, 0, 0);
-            if (idx < nchunks) nxt[it] = src[idx];
+        for (int it = 0; it < 8; ++it) {   // branch-free (a chunk past the plane re-reads chunk 0 and is never used): a load
+            const int idx = lane + 64 * it;   // under its bounds test waits for every earlier one (s_waitcnt vmcnt(0))
+            nxt[it] = src[idx < nchunks ? idx : 0];
         }
         if constexpr (BX) {
             const uint4* src2 = reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(bx.y) + plane * (long long)H * W);
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int idx = lane + 64 * it;
-                nxt2[it] = make_uint4(0, 0, 0, 0);
-                if (idx < nchunks) nxt2[it] = src2[idx];
+                nxt2[it] = src2[idx < nchunks ? idx : 0];
             }
         }
     };
@@ -816,8 +814,12 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_wgrad_vec_kernel(const T* __
 #pragma unroll
     for (int e = 0; e < K * K; ++e) acc[e] = 0.f;
     float xr[K][PXL];   // ring of x rows: slot m mod K holds row h0 - PAD + m
-    auto load_x = [&](int r) -> raw_t { return (live && r >= 0 && r < H) ? xp[(long long)r * Wq] : IO::zero(); };
-    auto load_g = [&](int h) -> raw_t { return (h < h1) ? dp[(long long)h * Wq] : IO::zero(); };
+    // ring loads, branch-free: a row outside the image / the group's chunk reads a clamped row and is zeroed when it is
+    // unpacked (a load under its bounds test waits for every earlier request -- s_waitcnt vmcnt(0) -- which serialized
+    // the ring: one round trip per row instead of K rows in flight)
+    auto load_x = [&](int r) -> raw_t { return xp[(long long)(r < 0 ? 0 : (r < H ? r : H - 1)) * Wq]; };
+    auto load_g = [&](int h) -> raw_t { return dp[(long long)(h < H ? h : H - 1) * Wq]; };
+    auto x_ok = [&](int r) { return live && r >= 0 && r < H; };
     float xsc = 1.f, xmu = 0.f, xb = 0.f;   // fused BN + ReLU6 of the x plane (wave-uniform channel)
     if constexpr (XF) {
         const int c = (int)(plane % C);
@@ -825,11 +827,14 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_wgrad_vec_kernel(const T* __
         xmu = xf.mean[c];
         xb = fmaf(xmu, xsc, xf.shift[c]);
     }
-    auto xform = [&](float* v, int r) {   // r = image row of the values; rows outside the image stay zero
+    auto xform = [&](float* v, int r) {   // r = image row of the values; rows outside the image are zero
+        const bool rv = x_ok(r);
         if constexpr (XF) {
-            const bool rv = live && r >= 0 && r < H;
 #pragma unroll
             for (int p = 0; p < PXL; ++p) v[p] = rv ? fminf(fmaxf(fmaf(v[p] - xmu, xsc, xb), 0.f), 6.f) : 0.f;
+        } else {
+#pragma unroll
+            for (int p = 0; p < PXL; ++p) v[p] = rv ? v[p] : 0.f;
         }
     };
 #pragma unroll
@@ -853,6 +858,10 @@ __global__ void __launch_bounds__(64 * DW_WAVES) dw_wgrad_vec_kernel(const T* __
             IO::unpack(rawx[u], xr[(u + K - 1) % K]);   // row h + PAD enters the ring
             xform(xr[(u + K - 1) % K], h + PAD);
             IO::unpack(rawg[u], gv);
+            if (h >= h1) {
+#pragma unroll
+                for (int p = 0; p < PXL; ++p) gv[p] = 0.f;
+            }
             rawx[u] = load_x(h + K + PAD);
             rawg[u] = load_g(h + K);
             build_window<PXL, PAD>(gv, gwin, lane, has_left, has_right);
