@@ -76,8 +76,42 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
 
+    // X window staging, fast form (K = 5: window start w0 - 2, so the aligned quads [w0 - 4, w0 + 36) cover it; W % 4 == 0,
+    // 16-byte aligned base): 5 quad requests per thread and chunk, all in flight together, branch-free (a quad outside
+    // the tensor reads the image's first quad and is zeroed by a mask).  The element loop below is one guarded scalar
+    // load per iteration, each waited for before the next: 18 serial round trips per chunk.
+    constexpr int XQ = (RW + 4) / 4, NQ = CF_KC * RH * XQ, NQT = (NQ + 255) / 256;
+    const bool fastx = KS == 5 && (W % 4 == 0) && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     for (int kc = 0; kc < nkc; ++kc) {
         __syncthreads();   // the previous chunk's readers are done with Xs / Ws
+        if (fastx) {
+            float4 q4[NQT];
+            uint32_t okm[NQT];
+#pragma unroll
+            for (int it = 0; it < NQT; ++it) {
+                const int idx = tid + 256 * it, ci = idx / (RH * XQ), rem = idx - ci * (RH * XQ), r = rem / XQ, jq = rem - r * XQ;
+                const int k = kc * CF_KC + ci, gh = h0 - P + r, gw = w0 - 4 + 4 * jq;
+                const bool ok = idx < NQ && k < Kdim && gh >= 0 && gh < H && gw >= 0 && gw < W;
+                okm[it] = ok ? 0xffffffffu : 0u;
+                q4[it] = *reinterpret_cast<const float4*>(xn + (ok ? (long long)k * plane + (long long)gh * W + gw : 0));
+            }
+#pragma unroll
+            for (int it = 0; it < NQT; ++it) {
+                const int idx = tid + 256 * it, ci = idx / (RH * XQ), rem = idx - ci * (RH * XQ), r = rem / XQ, jq = rem - r * XQ;
+                if (idx < NQ) {
+                    float* d = Xs + ci * XPL + r * RW + 4 * jq - 2;      // window columns 4 jq - 2 .. 4 jq + 1
+                    const uint32_t m = okm[it];
+                    if (jq > 0) {
+                        d[0] = __uint_as_float(__float_as_uint(q4[it].x) & m);
+                        d[1] = __uint_as_float(__float_as_uint(q4[it].y) & m);
+                    }
+                    if (jq < XQ - 1) {
+                        d[2] = __uint_as_float(__float_as_uint(q4[it].z) & m);
+                        d[3] = __uint_as_float(__float_as_uint(q4[it].w) & m);
+                    }
+                }
+            }
+        } else
         for (int e = tid; e < CF_KC * RH * RW; e += 256) {
             const int ci = e / (RH * RW), r = (e - ci * (RH * RW)) / RW, col = e - ci * (RH * RW) - r * RW;
             const int k = kc * CF_KC + ci, gh = h0 - P + r, gw = w0 - P + col;
