@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) conv_f32_prep_kernel(const float* __restr
 }
 
 template <int KS>
-__global__ void __launch_bounds__(256) conv_f32_kernel(const float* __restrict__ x, const float* __restrict__ wimg,
+__global__ void __launch_bounds__(256, 3) conv_f32_kernel(const float* __restrict__ x, const float* __restrict__ wimg,
                                                        float* __restrict__ y, int Kdim, int M, int Mpad, int H, int W,
                                                        int tiles_x, int nkc) {
     constexpr int P = KS / 2;
@@ -122,11 +122,20 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(const float* __restrict__
         for (int ty = 0; ty < KS; ++ty) {
             if (ty) __syncthreads();   // the previous kernel row's readers are done with Ws
             {
+                // the slab's KS quads per thread are requested together, then written (as a rolled loop every request was
+                // waited for before the next: KS serial L2 round trips per kernel row)
                 const float4* src = reinterpret_cast<const float4*>(wimg + ((long long)(kc * KS + ty) * KS) * CF_KC * Mpad);
-                for (int q = tid; q < KS * CF_KC * (CF_MB / 4); q += 256) {
+                constexpr int NWQ = KS * CF_KC * (CF_MB / 4) / 256;
+                static_assert(KS * CF_KC * (CF_MB / 4) % 256 == 0, "whole rounds of the block");
+                float4 wq[NWQ];
+#pragma unroll
+                for (int it = 0; it < NWQ; ++it) {
+                    const int q = tid + 256 * it;
                     const int m4 = q % (CF_MB / 4), rest = q / (CF_MB / 4);   // rest = tx*16 + kk
-                    reinterpret_cast<float4*>(Ws)[q] = src[(long long)rest * (Mpad / 4) + slab * (CF_MB / 4) + m4];
+                    wq[it] = src[(long long)rest * (Mpad / 4) + slab * (CF_MB / 4) + m4];
                 }
+#pragma unroll
+                for (int it = 0; it < NWQ; ++it) reinterpret_cast<float4*>(Ws)[tid + 256 * it] = wq[it];
             }
             __syncthreads();
 #pragma unroll
