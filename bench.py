@@ -18,7 +18,10 @@ Prints ONE JSON line on rank 0.  Besides the contract fields it carries
                 (hipExtLaunchKernel start / stop events, ofasr_profile_enable in include/ofasr.h: the kernel's begin -> end
                 time as rocprofv3's kernel trace reports it, no barrier packets added, streams overlap as in the timed
                 region) on the SAME composite path the timed region runs; `trace_avg_us` beside it is the average of the
-                same symbol in the committed rocprofv3 trace of the same command (profiles/trace_summary.json, static);
+                same symbol in the committed rocprofv3 trace of the same command (profiles/trace_summary.json, static),
+                `serialized_avg_us` the same with the dispatches serialized (the counter pass: the kernel alone on the
+                GPU) -- a kernel's duration in the step depends on what the other stream runs beside it, so the three
+                bracket it: serialized <= live events <= concurrent trace;
   kernels       the per-kernel table of those profiled steps (symbol = the name rocprofv3 prints);
   pointwise     the 1x1 path's MFMA TFLOP/s against the MFMA peak of the dtype (north_star quotes its target against it);
   fp32          (c3, dtype != f32) the same training step with fp32 activations -- the reference's arithmetic -- as a
@@ -292,6 +295,7 @@ def roofline_from(summ, nprof, dtype):
     mfma_bound = top["flops"] > 0 and top["flops"] / top["bytes"] > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
     traffic, source = pmc_traffic(name)
     trace_us, trace_src = trace_avg(name, dtype)
+    ser_us, ser_src = trace_avg(name, dtype + "_serialized")
     if mfma_bound:
         ach = top["flops"] / secs / 1e12
         roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 1), "peak": peak_tf, "unit": "TFLOP/s",
@@ -311,6 +315,12 @@ def roofline_from(summ, nprof, dtype):
                  "frac_trace": (round((top["flops"] if mfma_bound else top["bytes"]) / top["launches"] / (trace_us * 1e-6)
                                       / ((peak_tf * 1e12) if mfma_bound else (HBM_PEAK_GBS * 1e9)), 4)
                                 if trace_us else None),
+                 # the same symbol with the dispatches serialized (the counter pass of the same command): the kernel alone
+                 # on the GPU.  trace_avg_us is what the step pays with the other stream's kernels on the same CUs.
+                 "serialized_avg_us": ser_us, "serialized_source": ser_src,
+                 "frac_serialized": (round((top["flops"] if mfma_bound else top["bytes"]) / top["launches"] / (ser_us * 1e-6)
+                                           / ((peak_tf * 1e12) if mfma_bound else (HBM_PEAK_GBS * 1e9)), 4)
+                                     if ser_us else None),
                  "timing": "start/stop events attached to each kernel dispatch (hipExtLaunchKernel), composite path, "
                            "%d profiled steps, both streams live" % nprof,
                  "hip_library_ms_per_step": round(sum(v["total_us"] for v in summ.values()) * 1e-3 / nprof, 3)})

@@ -73,7 +73,10 @@ def main():
         table = {}
         if os.path.exists(out):
             table = json.load(open(out))
-        table[key] = {"source": "rocprofv3 --kernel-trace of `bench.py --dtype %s`, last %d timed steps" % (key, nsteps),
+        ser = key.endswith("_serialized")
+        table[key] = {"source": ("rocprofv3 --kernel-trace --pmc FETCH_SIZE of `bench.py --dtype %s` (dispatches serialized: each "
+                                 "kernel alone on the GPU), last %d timed steps" % (key[:-len("_serialized")], nsteps)) if ser else
+                                "rocprofv3 --kernel-trace of `bench.py --dtype %s`, last %d timed steps" % (key, nsteps),
                       "wall_ms_per_step": round(span / nsteps, 3), "gpu_active_ms_per_step": round(union / 1e6 / nsteps, 3),
                       "kernels": {site_name(n): {"avg_us": round(t / 1e3 / c, 2), "launches_per_step": round(c / nsteps, 2),
                                                  "ms_per_step": round(t / 1e6 / nsteps, 4)}

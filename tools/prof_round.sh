@@ -27,6 +27,9 @@ leg() {   # leg <dtype> <suffix> <steps> <warmup> <steps aggregated>
     cp "$(find /tmp/pk -name "*kernel_stats.csv" | head -1)" $OUT/${TAG}${SFX}_kernel_stats.csv
     echo "$DT trace done" >> $OUT/${TAG}_prof.log
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- python3 $R/bench.py --dtype $DT --steps 5 --warmup 3 $COMMON > /dev/null 2>> $OUT/${TAG}${SFX}_prof.err
+    # the counter pass serializes the dispatches: its kernel trace = every kernel's duration WITHOUT the other stream
+    # beside it (trace_summary.json key <dtype>_serialized; bench.py: roofline.serialized_avg_us / frac_serialized)
+    python3 $R/profiles/trace_steps.py "$(find /tmp/pf -name "*kernel_trace.csv" | head -1)" 3 80 0 "$SUMM" ${DT}_serialized > $OUT/${TAG}${SFX}_serialized_steps.txt
     echo "$DT fetch done" >> $OUT/${TAG}_prof.log
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- python3 $R/bench.py --dtype $DT --steps 5 --warmup 3 $COMMON > /dev/null 2>> $OUT/${TAG}${SFX}_prof.err
     python3 $R/tools/pmc_traffic.py /tmp/pf /tmp/pw "$PMCJ" --merge > $OUT/${TAG}${SFX}_pmc_traffic.txt
