@@ -20,8 +20,9 @@ Prints ONE JSON line on rank 0.  Besides the contract fields it carries
                 region) on the SAME composite path the timed region runs; `trace_avg_us` beside it is the average of the
                 same symbol in the committed rocprofv3 trace of the same command (profiles/trace_summary.json, static),
                 `serialized_avg_us` the same with the dispatches serialized (the counter pass: the kernel alone on the
-                GPU) -- a kernel's duration in the step depends on what the other stream runs beside it, so the three
-                bracket it: serialized <= live events <= concurrent trace;
+                GPU) -- a kernel's duration in the step depends on what the other stream runs beside it: the serialized
+                figure is the kernel's own, the concurrent trace what the step pays, the live events lie between (or
+                at the serialized figure for a side-stream kernel that the instrumented steps happen to run alone);
   kernels       the per-kernel table of those profiled steps (symbol = the name rocprofv3 prints);
   pointwise     the 1x1 path's MFMA TFLOP/s against the MFMA peak of the dtype (north_star quotes its target against it);
   fp32          (c3, dtype != f32) the same training step with fp32 activations -- the reference's arithmetic -- as a
