@@ -93,6 +93,61 @@ __device__ __forceinline__ void lds_store_w(char* base, int off, float v) {
 // Vector form: every thread issues all of its 16-byte global loads first (ROWS/16 independent loads in
 // flight), then converts and writes LDS -- the slice is L2-resident, so this is latency-, not
 // bandwidth-limited and the loads must overlap.  Needs w 16-byte aligned and ldw % 4 == 0 (WVEC).
+// A [ROWS x 64] weight chunk in registers (vector-loadable slices whose 4-element chunks are wholly inside or outside:
+// K % 4 == 0 row-major, M % 4 == 0 transposed): wchunk_request issues all requests branch-free -- an outside chunk reads
+// the slice's first chunk -- and wchunk_deposit writes them to the operand tile, zeroing the outside ones.  (A load under
+// its bounds test ends the basic block with s_waitcnt vmcnt(0): NIT serial L2 round trips per tile.)
+template <int ROWS> struct WChunk {
+    static constexpr int NIT = ROWS * 16 / PW_THREADS;   // float4 chunks per thread
+    float4 v[NIT];
+    uint32_t ok;
+};
+__device__ __forceinline__ bool wchunk_whole(const WView& wv) { return wv.sk == 1 ? (wv.K % 4 == 0) : (wv.M % 4 == 0); }
+template <int ROWS>
+__device__ __forceinline__ void wchunk_request(WChunk<ROWS>& g, const WView& wv, int m0, int k0) {
+    const int tid = threadIdx.x;
+    g.ok = 0;
+#pragma unroll
+    for (int it = 0; it < WChunk<ROWS>::NIT; ++it) {
+        const int q = tid + it * PW_THREADS;
+        long long off;
+        bool ok;
+        if (wv.sk == 1) {
+            const int r = q >> 4, k = 4 * (q & 15);
+            ok = m0 + r < wv.M && k0 + k < wv.K;
+            off = (long long)(m0 + r) * wv.sm + k0 + k;
+        } else {
+            const int k = q / (ROWS / 4), r = 4 * (q - k * (ROWS / 4));
+            ok = k0 + k < wv.K && m0 + r < wv.M;
+            off = (long long)(k0 + k) * wv.sk + m0 + r;
+        }
+        g.v[it] = *reinterpret_cast<const float4*>(wv.w + (ok ? off : 0));
+        g.ok |= (ok ? 1u : 0u) << it;
+    }
+}
+template <typename T, int ROWS>
+__device__ __forceinline__ void wchunk_deposit(char* Wt, const WChunk<ROWS>& g, const WView& wv) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < WChunk<ROWS>::NIT; ++it) {
+        const int q = tid + it * PW_THREADS;
+        const float4 t = (g.ok >> it) & 1u ? g.v[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wv.sk == 1) {
+            const int r = q >> 4, k = 4 * (q & 15);
+            if constexpr (Elem<T>::is16)
+                *reinterpret_cast<uint2*>(Wt + wtile_off<T>(r, k)) = make_uint2(pack2<T>(t.x, t.y), pack2<T>(t.z, t.w));
+            else
+                *reinterpret_cast<float4*>(Wt + wtile_off<T>(r, k)) = t;
+        } else {
+            const int k = q / (ROWS / 4), r = 4 * (q - k * (ROWS / 4));
+            lds_store_w<T>(Wt, wtile_off<T>(r, k), t.x);
+            lds_store_w<T>(Wt, wtile_off<T>(r + 1, k), t.y);
+            lds_store_w<T>(Wt, wtile_off<T>(r + 2, k), t.z);
+            lds_store_w<T>(Wt, wtile_off<T>(r + 3, k), t.w);
+        }
+    }
+}
+
 template <typename T, int ROWS, bool WVEC>
 __device__ __forceinline__ void stage_w_tile(char* Wt, const WView& wv, int m0, int k0) {
     const int tid = threadIdx.x;
@@ -115,44 +170,10 @@ __device__ __forceinline__ void stage_w_tile(char* Wt, const WView& wv, int m0, 
     } else {
         constexpr int NIT = ROWS * 16 / PW_THREADS;  // float4 chunks per thread
         float4 v[NIT];
-        // slices whose chunks are wholly inside or outside (K % 4 == 0 row-major, M % 4 == 0 transposed; uniform): all
-        // requests issued branch-free -- an outside chunk reads the slice's first chunk and is zeroed -- because a load
-        // under its bounds test ends the basic block with s_waitcnt vmcnt(0): NIT serial L2 round trips per tile
-        if (wv.sk == 1 ? (wv.K % 4 == 0) : (wv.M % 4 == 0)) {
-            bool okv[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int q = tid + it * PW_THREADS;
-                long long off;
-                if (wv.sk == 1) {
-                    const int r = q >> 4, k = 4 * (q & 15);
-                    okv[it] = m0 + r < wv.M && k0 + k < wv.K;
-                    off = (long long)(m0 + r) * wv.sm + k0 + k;
-                } else {
-                    const int k = q / (ROWS / 4), r = 4 * (q - k * (ROWS / 4));
-                    okv[it] = k0 + k < wv.K && m0 + r < wv.M;
-                    off = (long long)(k0 + k) * wv.sk + m0 + r;
-                }
-                v[it] = *reinterpret_cast<const float4*>(wv.w + (okv[it] ? off : 0));
-            }
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int q = tid + it * PW_THREADS;
-                const float4 t = okv[it] ? v[it] : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (wv.sk == 1) {
-                    const int r = q >> 4, k = 4 * (q & 15);
-                    if constexpr (Elem<T>::is16)
-                        *reinterpret_cast<uint2*>(Wt + wtile_off<T>(r, k)) = make_uint2(pack2<T>(t.x, t.y), pack2<T>(t.z, t.w));
-                    else
-                        *reinterpret_cast<float4*>(Wt + wtile_off<T>(r, k)) = t;
-                } else {
-                    const int k = q / (ROWS / 4), r = 4 * (q - k * (ROWS / 4));
-                    lds_store_w<T>(Wt, wtile_off<T>(r, k), t.x);
-                    lds_store_w<T>(Wt, wtile_off<T>(r + 1, k), t.y);
-                    lds_store_w<T>(Wt, wtile_off<T>(r + 2, k), t.z);
-                    lds_store_w<T>(Wt, wtile_off<T>(r + 3, k), t.w);
-                }
-            }
+        if (wchunk_whole(wv)) {   // uniform
+            WChunk<ROWS> g;
+            wchunk_request<ROWS>(g, wv, m0, k0);
+            wchunk_deposit<T, ROWS>(Wt, g, wv);
             return;
         }
         if (wv.sk == 1) {  // row-major slice: chunk = 4 consecutive k of one row
@@ -264,51 +285,74 @@ __device__ __forceinline__ uint4 bx_apply8(uint4 g, uint4 yv, float mu, float sc
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// A [64 channels x 128 pixels] X chunk in registers (aligned tensors: 16-byte vectors wholly inside or outside): request
+// = all vectors issued branch-free (a vector outside the tensor reads the image's first one), deposit = fused BN + ReLU6
+// where asked for, zero the outside ones, write the staging layout of stage_x_tile.
+template <typename T> struct XChunk {
+    static constexpr int NIT = Elem<T>::is16 ? 4 : 8;     // 16-byte vectors per thread
+    static constexpr int VPR = Elem<T>::is16 ? 16 : 32;   // vectors per channel row
+    static constexpr int EPV = Elem<T>::is16 ? 8 : 4;     // elements per vector
+    uint4 v[NIT];
+    uint32_t ok;
+};
+template <typename T>
+__device__ __forceinline__ void xchunk_request(XChunk<T>& g, const T* __restrict__ xn, int K, int HW, int k0, int p0) {
+    const int tid = threadIdx.x;
+    g.ok = 0;
+#pragma unroll
+    for (int it = 0; it < XChunk<T>::NIT; ++it) {
+        const int q = tid + it * PW_THREADS;
+        const int k = q / XChunk<T>::VPR, m = q % XChunk<T>::VPR;
+        const int px = p0 + XChunk<T>::EPV * m;
+        const bool ok = k0 + k < K && px < HW;
+        g.v[it] = *reinterpret_cast<const uint4*>(xn + (ok ? (long long)(k0 + k) * HW + px : 0));
+        g.ok |= (ok ? 1u : 0u) << it;
+    }
+}
+template <typename T, int PX, bool XF>
+__device__ __forceinline__ void xchunk_deposit(char* Xs, const XChunk<T>& g, int K, int k0, InputXf xf) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < XChunk<T>::NIT; ++it) {
+        const int q = tid + it * PW_THREADS;
+        const int k = q / XChunk<T>::VPR, m = q % XChunk<T>::VPR;
+        uint4 v = g.v[it];
+        if constexpr (Elem<T>::is16 && XF) v = xf_apply8<T>(v, xf, k0 + k < K ? k0 + k : K - 1);
+        const uint32_t msk = (g.ok >> it) & 1u ? 0xffffffffu : 0u;
+        v = make_uint4(v.x & msk, v.y & msk, v.z & msk, v.w & msk);
+        if constexpr (Elem<T>::is16) {
+            char* row = Xs + k * XROW16;
+            if (PX == 4) {
+                // pixel 8m+i -> position 32*(i&3) + 2m + (i>>2): pairs (i, i+4) are adjacent
+                uint32_t* r32 = reinterpret_cast<uint32_t*>(row);
+                r32[(32 * 0 + 2 * m) >> 1] = (v.x & 0xffffu) | (v.z << 16);
+                r32[(32 * 1 + 2 * m) >> 1] = (v.x >> 16) | (v.z & 0xffff0000u);
+                r32[(32 * 2 + 2 * m) >> 1] = (v.y & 0xffffu) | (v.w << 16);
+                r32[(32 * 3 + 2 * m) >> 1] = (v.y >> 16) | (v.w & 0xffff0000u);
+            } else {
+                // pixel 8m+i -> position 64*(m>>3) + 32*(i&1) + 4*(m&7) + (i>>1)
+                const int base = 64 * (m >> 3) + 4 * (m & 7);
+                const uint2 ev = make_uint2((v.x & 0xffffu) | (v.y << 16), (v.z & 0xffffu) | (v.w << 16));
+                const uint2 od = make_uint2((v.x >> 16) | (v.y & 0xffff0000u), (v.z >> 16) | (v.w & 0xffff0000u));
+                *reinterpret_cast<uint2*>(row + (base)*2) = ev;
+                *reinterpret_cast<uint2*>(row + (base + 32) * 2) = od;
+            }
+        } else {
+            *reinterpret_cast<uint4*>(Xs + k * XROW32 + m * 16) = v;
+        }
+    }
+}
+
 template <typename T, int PX, bool ALIGNED, bool XF = false>
 __device__ __forceinline__ void stage_x_tile(char* Xs, const T* __restrict__ xn, int K, int HW, int k0, int p0,
                                              InputXf xf = InputXf{}) {
     const int tid = threadIdx.x;
     if constexpr (Elem<T>::is16) {
         if (ALIGNED) {
-            // 64 rows x 16 chunks of 8 pixels (16 B); HW % 8 == 0 so a chunk is all-in or all-out.  All four requests are
-            // issued before the first use, branch-free (a chunk outside the tensor reads the image's first chunk and is
-            // zeroed below): a load under its bounds test ends the basic block with s_waitcnt vmcnt(0) -- one round trip
-            // per request
-            uint4 vv[4];
-            bool okv[4];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int q = tid + it * PW_THREADS;
-                const int k = q >> 4, m = q & 15;
-                const int px = p0 + 8 * m;
-                okv[it] = k0 + k < K && px < HW;
-                vv[it] = *reinterpret_cast<const uint4*>(xn + (okv[it] ? (long long)(k0 + k) * HW + px : 0));
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int q = tid + it * PW_THREADS;
-                const int k = q >> 4, m = q & 15;
-                uint4 v = vv[it];
-                if constexpr (XF) v = xf_apply8<T>(v, xf, k0 + k < K ? k0 + k : K - 1);
-                const uint32_t msk = okv[it] ? 0xffffffffu : 0u;
-                v = make_uint4(v.x & msk, v.y & msk, v.z & msk, v.w & msk);
-                char* row = Xs + k * XROW16;
-                if (PX == 4) {
-                    // pixel 8m+i -> position 32*(i&3) + 2m + (i>>2): pairs (i, i+4) are adjacent
-                    uint32_t* r32 = reinterpret_cast<uint32_t*>(row);
-                    r32[(32 * 0 + 2 * m) >> 1] = (v.x & 0xffffu) | (v.z << 16);
-                    r32[(32 * 1 + 2 * m) >> 1] = (v.x >> 16) | (v.z & 0xffff0000u);
-                    r32[(32 * 2 + 2 * m) >> 1] = (v.y & 0xffffu) | (v.w << 16);
-                    r32[(32 * 3 + 2 * m) >> 1] = (v.y >> 16) | (v.w & 0xffff0000u);
-                } else {
-                    // pixel 8m+i -> position 64*(m>>3) + 32*(i&1) + 4*(m&7) + (i>>1)
-                    const int base = 64 * (m >> 3) + 4 * (m & 7);
-                    uint2 ev = make_uint2((v.x & 0xffffu) | (v.y << 16), (v.z & 0xffffu) | (v.w << 16));
-                    uint2 od = make_uint2((v.x >> 16) | (v.y & 0xffff0000u), (v.z >> 16) | (v.w & 0xffff0000u));
-                    *reinterpret_cast<uint2*>(row + (base)*2) = ev;
-                    *reinterpret_cast<uint2*>(row + (base + 32) * 2) = od;
-                }
-            }
+            // 64 rows x 16 vectors of 8 pixels (16 B); HW % 8 == 0 so a vector is all-in or all-out
+            XChunk<T> g;
+            xchunk_request<T>(g, xn, K, HW, k0, p0);
+            xchunk_deposit<T, PX, XF>(Xs, g, K, k0, xf);
         } else {
             for (int e = tid; e < 64 * PW_TILE; e += PW_THREADS) {
                 const int k = e >> 7, q = e & 127;
@@ -320,24 +364,10 @@ __device__ __forceinline__ void stage_x_tile(char* Xs, const T* __restrict__ xn,
         }
     } else {
         if (ALIGNED) {
-            // 64 rows x 32 chunks of 4 pixels (16 B); HW % 4 == 0; the eight requests together, branch-free (as above)
-            uint4 vv[8];
-            bool okv[8];
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int q = tid + it * PW_THREADS;
-                const int k = q >> 5, m = q & 31;
-                const int px = p0 + 4 * m;
-                okv[it] = k0 + k < K && px < HW;
-                vv[it] = *reinterpret_cast<const uint4*>(xn + (okv[it] ? (long long)(k0 + k) * HW + px : 0));
-            }
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int q = tid + it * PW_THREADS;
-                const int k = q >> 5, m = q & 31;
-                const uint32_t msk = okv[it] ? 0xffffffffu : 0u;
-                *reinterpret_cast<uint4*>(Xs + k * XROW32 + m * 16) = make_uint4(vv[it].x & msk, vv[it].y & msk, vv[it].z & msk, vv[it].w & msk);
-            }
+            // 64 rows x 32 vectors of 4 pixels (16 B); HW % 4 == 0
+            XChunk<T> g;
+            xchunk_request<T>(g, xn, K, HW, k0, p0);
+            xchunk_deposit<T, PX, XF>(Xs, g, K, k0, xf);
         } else {
             for (int e = tid; e < 64 * PW_TILE; e += PW_THREADS) {
                 const int k = e >> 7, q = e & 127;
@@ -822,11 +852,30 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_kernel(const T* __restric
     acc[0] = zero16();
     acc[1] = zero16();
     const int row = 32 * cb + c;
+    // aligned tensors and vector-loadable weights: chunk kc + 1 is requested into registers before the MFMAs of chunk kc
+    // (as pw_fanin_pipe_kernel, which serves the 16-bit hot shapes; this is what the fp32 1x1 forward / input gradient
+    // run on): its round trip runs under the round instead of after it
+    const bool piped = ALIGNED && WVEC && wchunk_whole(wv);   // uniform
+    XChunk<T> xg;
+    WChunk<64> wg;
+    if (piped) {
+        xchunk_request<T>(xg, xn, wv.K, HW, 0, p0);
+        wchunk_request<64>(wg, wv, m_base, 0);
+    }
     for (int kc = 0; kc < kchunks; ++kc) {
         if (kc) __syncthreads();
-        stage_x_tile<T, 2, ALIGNED, XF>(Xs, xn, wv.K, HW, kc * 64, p0, xf);
-        stage_w_tile<T, 64, WVEC>(Ws, wv, m_base, kc * 64);
+        if (piped) {
+            xchunk_deposit<T, 2, XF>(Xs, xg, wv.K, kc * 64, xf);
+            wchunk_deposit<T, 64>(Ws, wg, wv);
+        } else {
+            stage_x_tile<T, 2, ALIGNED, XF>(Xs, xn, wv.K, HW, kc * 64, p0, xf);
+            stage_w_tile<T, 64, WVEC>(Ws, wv, m_base, kc * 64);
+        }
         __syncthreads();
+        if (piped && kc + 1 < kchunks) {
+            xchunk_request<T>(xg, xn, wv.K, HW, (kc + 1) * 64, p0);
+            wchunk_request<64>(wg, wv, m_base, (kc + 1) * 64);
+        }
         if constexpr (Elem<T>::is16) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
