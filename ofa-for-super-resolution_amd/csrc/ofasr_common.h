@@ -129,11 +129,18 @@ template <> __device__ __forceinline__ f16_t from_float<f16_t>(float x) {
     return r;
 }
 
+// the pair as ONE vector conversion: v_cvt_pk_bf16_f32 dst, lo, hi (RNE, as the scalar cast).  Converting the halves
+// separately and OR-ing them costs three instructions per pair (cvt, cvt-or via SDWA, shift).
+typedef float ofasr_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ofasr_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 ofasr_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
-    return (uint32_t)from_float<bf16_t>(lo).v | ((uint32_t)from_float<bf16_t>(hi).v << 16);
+    const ofasr_f32x2 f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, ofasr_bf16x2));
 }
 __device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
-    return (uint32_t)from_float<f16_t>(lo).v | ((uint32_t)from_float<f16_t>(hi).v << 16);
+    const ofasr_f32x2 f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, ofasr_f16x2));
 }
 // the two 16-bit values of a packed word -> fp32
 template <typename T> __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi);
