@@ -1131,10 +1131,12 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __re
     };
     auto store_chunk = [&](int kc) {
         if constexpr (FAST) {
+            if (okbits != 0xffu) {   // a lane with every chunk inside (all lanes of an interior tile) skips 32 selects per round
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                if (!((okbits >> it) & 1u)) wr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!((okbits >> (4 + it)) & 1u)) xr[it] = make_uint4(0, 0, 0, 0);
+                for (int it = 0; it < 4; ++it) {
+                    if (!((okbits >> it) & 1u)) wr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!((okbits >> (4 + it)) & 1u)) xr[it] = make_uint4(0, 0, 0, 0);
+                }
             }
         }
 #pragma unroll
