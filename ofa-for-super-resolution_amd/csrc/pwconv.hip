@@ -1056,6 +1056,27 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __re
     uint4 yr[BX ? 4 : 1];
     float4 wr[4];
     uint32_t okbits = 0;   // FAST: bit it = weight chunk it is inside the slice, bit 4+it = X vector it is
+    // FAST: this lane's element offsets inside a 64-channel chunk (X / y: relative to the chunk's first channel row;
+    // weights: relative to the slice's element (k0, 0) resp. (0, k0)) and the chunk-independent halves of the bounds tests
+    uint32_t xoff[FAST ? 4 : 1], woff[FAST ? 4 : 1], xpx_ok = 0, wrow_ok = 0;
+    if constexpr (FAST) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int q = tid + it * PW_THREADS;
+            const int px = p0 + 8 * (q & 15);
+            xoff[it] = (uint32_t)(q >> 4) * (uint32_t)HW + (uint32_t)px;
+            xpx_ok |= (px < HW ? 1u : 0u) << it;
+            if (rowmajor) {
+                const int r = q >> 4;
+                woff[it] = (uint32_t)(m_base + r) * (uint32_t)wv.sm + 4u * (q & 15);
+                wrow_ok |= (r < mloc ? 1u : 0u) << it;
+            } else {
+                const int r = 4 * (q & 15);
+                woff[it] = (uint32_t)(q >> 4) * (uint32_t)wv.sk + (uint32_t)(m_base + r);
+                wrow_ok |= (m_base + r < wv.M ? 1u : 0u) << it;
+            }
+        }
+    }
     auto load_chunk = [&](int kc) {
         const int k0 = 64 * kc;
         if constexpr (FAST) {
@@ -1063,31 +1084,29 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __re
             // Branch-free: an outside chunk reads the first chunk instead and is zeroed when it is written to LDS -- a
             // conditional load ends its basic block with s_waitcnt vmcnt(0), which made the 4 weight requests of a
             // round 4 serial L2 round trips
+            // Addresses = uniform chunk base + a 32-bit element offset that each lane computes ONCE (xoff / woff below;
+            // launch condition: the image and the weight slice span < 2^31 elements): with (long long)k * HW + px formed
+            // per request the kernel issued ~70 quarter-rate 32-bit multiplies and as many 64-bit adds per round.
             okbits = 0;
+            const float* wk = wv.w + (long long)k0 * (rowmajor ? 1 : wv.sk);              // uniform
+            const uint32_t wfirst = (uint32_t)m_base * (rowmajor ? (uint32_t)wv.sm : 1u);   // a chunk that is always inside
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int q = tid + it * PW_THREADS;
-                long long off;
-                bool ok;
-                if (rowmajor) {
-                    const int r = q >> 4, kk = k0 + 4 * (q & 15);
-                    ok = r < mloc && kk < wv.K;
-                    off = (long long)(m_base + r) * wv.sm + kk;
-                } else {
-                    const int k = q >> 4, r = 4 * (q & 15);
-                    ok = k0 + k < wv.K && m_base + r < wv.M;
-                    off = (long long)(k0 + k) * wv.sk + m_base + r;
-                }
-                wr[it] = *reinterpret_cast<const float4*>(wv.w + (ok ? off : 0));
+                const bool ok = rowmajor ? ((wrow_ok >> it) & 1u) && k0 + 4 * (q & 15) < wv.K
+                                         : ((wrow_ok >> it) & 1u) && k0 + (q >> 4) < wv.K;
+                wr[it] = *reinterpret_cast<const float4*>(wk + (ok ? woff[it] : wfirst));
                 okbits |= (ok ? 1u : 0u) << it;
             }
+            const T* xk = xn + (long long)k0 * HW;                                          // uniform
+            const T* yk = BX ? yn2 + (long long)k0 * HW : nullptr;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int q = tid + it * PW_THREADS;
-                const int k = k0 + (q >> 4), px = p0 + 8 * (q & 15);
-                const bool ok = k < wv.K && px < HW;
-                xr[it] = *reinterpret_cast<const uint4*>(xn + (ok ? (long long)k * HW + px : 0));
-                if constexpr (BX) yr[it] = *reinterpret_cast<const uint4*>(yn2 + (ok ? (long long)k * HW + px : 0));
+                const bool ok = ((xpx_ok >> it) & 1u) && k0 + (q >> 4) < wv.K;
+                const uint32_t off = ok ? xoff[it] : (uint32_t)p0;
+                xr[it] = *reinterpret_cast<const uint4*>(xk + off);
+                if constexpr (BX) yr[it] = *reinterpret_cast<const uint4*>(yk + off);
                 okbits |= (ok ? 16u : 0u) << it;
             }
             return;
@@ -1171,8 +1190,8 @@ __global__ void __launch_bounds__(PW_THREADS) pw_fanin_pipe_kernel(const T* __re
                     v = bx_apply8<T>(v, yr[it], bxt[ch], bxt[FOLD_KMAX + ch], bxt[2 * FOLD_KMAX + ch], bxt[3 * FOLD_KMAX + ch],
                                      bxt[4 * FOLD_KMAX + ch]);
                     // the tile's dy, once (the blocks of the first output-row slab), for the weight-gradient kernel
-                    if (bx.dy_out && blockIdx.y == 0)
-                        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(bx.dy_out) + ((long long)n * wv.K + ch) * HW + p0 + 8 * m) = v;
+                    if (bx.dy_out && blockIdx.y == 0)   // same element offset as the request: uniform chunk base + xoff
+                        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(bx.dy_out) + ((long long)n * wv.K + 64 * kc) * HW + xoff[it]) = v;
                 }
             }
             // pixel 8m+i -> position 64*(m>>3) + 32*(i&1) + 4*(m&7) + (i>>1)   (stage_x_tile, PX = 2)
@@ -1779,7 +1798,9 @@ static void launch_gemm_v(const void* x, WView wv, void* y, int64_t HW, int tile
         dim3 grid((unsigned)total_tiles, (unsigned)cdiv(wv.M, 64));
         if constexpr (Elem<T>::is16 && AL && WV) {
             static const bool fast_ok = [] { const char* e = getenv("OFASR_PW_FANIN_FAST"); return !(e && e[0] == '0'); }();
-            if (fast_ok && wv.K % 4 == 0 && wv.M % 4 == 0)
+            const bool span32 = (long long)wv.K * HW < (1LL << 31) &&
+                                (long long)wv.M * wv.sm + (long long)wv.K * wv.sk < (1LL << 31);   // 32-bit lane offsets
+            if (fast_ok && wv.K % 4 == 0 && wv.M % 4 == 0 && span32)
                 OFASR_LAUNCH((pw_fanin_pipe_kernel<T, XF, true>), grid, dim3(PW_THREADS), 0, st, (const T*)x, wv,
                                    (T*)y, (int)HW, tiles_per_img, (int)cdiv(wv.K, 64), xf, (const T*)addend, so, fold);
             else
@@ -1953,7 +1974,7 @@ bool pwconv_dgrad_bx_supported(const void* da, const void* y, const void* dx, co
                            reinterpret_cast<uintptr_t>(addend) | reinterpret_cast<uintptr_t>(w);   // dy_out: checked by the caller
     static const bool fast_ok = [] { const char* e = getenv("OFASR_PW_FANIN_FAST"); return !(e && e[0] == '0'); }();
     return fast_ok && (bits & 15) == 0 && HW % 8 == 0 && ldw % 4 == 0 && Cin % 4 == 0 && Cout % 4 == 0 && Cout > 64 &&
-           Cout <= FOLD_KMAX;
+           Cout <= FOLD_KMAX && Cout * HW < (1LL << 31) && (Cin + Cout) * ldw < (1LL << 31);   // 32-bit lane offsets
 }
 
 template <typename T>
