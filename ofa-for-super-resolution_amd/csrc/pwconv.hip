@@ -467,10 +467,17 @@ __device__ __forceinline__ void stat_epilogue(const f32x16* acc, int px, int HW,
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         float ss = 0.f, qq = 0.f;
+        float vs[NSUB];
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t) vs[t] = acc[t][reg];
+        if constexpr (Elem<T>::is16) {   // the values as stored: rounded through the very pair conversions the store issues
+            static_assert(NSUB % 2 == 0, "pairs");
+#pragma unroll
+            for (int t = 0; t < NSUB; t += 2) unpack2<T>(pack2<T>(vs[t], vs[t + 1]), vs[t], vs[t + 1]);
+        }
 #pragma unroll
         for (int t = 0; t < NSUB; ++t) {
-            float v = acc[t][reg];
-            if constexpr (Elem<T>::is16) v = to_float(from_float<T>(v));   // the values as stored
+            const float v = vs[t];
             if (px + t < HW) {
                 ss += v;
                 qq = fmaf(v, v, qq);
@@ -800,11 +807,13 @@ pw_fanout_slabs_kernel(const T* __restrict__ x, WView wv, T* __restrict__ y, int
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 float ss = 0.f, qq = 0.f;
+                float vs[4];   // the values as stored: unpacked from the very pair conversions the store above issued
+                unpack2<T>(pack2<T>(acc[0][reg], acc[1][reg]), vs[0], vs[1]);
+                unpack2<T>(pack2<T>(acc[2][reg], acc[3][reg]), vs[2], vs[3]);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const float v = to_float(from_float<T>(acc[t][reg]));   // the values as stored
-                    ss += v;
-                    qq = fmaf(v, v, qq);
+                    ss += vs[t];
+                    qq = fmaf(vs[t], vs[t], qq);
                 }
                 sv[reg] = ss;
                 qv[reg] = qq;
@@ -1556,6 +1565,10 @@ __global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restric
             bkbi[rb] = bx.kbi[rowc[rb]];
         }
     }
+    long long rowoff[WD_RB];   // element offset of this lane's rows / column inside an image
+#pragma unroll
+    for (int rb = 0; rb < WD_RB; ++rb) rowoff[rb] = (long long)rowc[rb] * HW;
+    const long long coloff = (long long)colc * HW;
     for (int q = q0; q < q1; ++q) {
         const int n = q / wp.quads_per_img;
         const int px = (q - n * wp.quads_per_img) * 64 + 32 * h;   // this lane's first pixel
@@ -1570,25 +1583,27 @@ __global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restric
             okp[j] = px + 8 * j < HW;
             pxc[j] = okp[j] ? px + 8 * j : 0;
         }
-        const T* sp = S + ((long long)n * NS + colc) * HW;
+        // uniform image base + the lane's row offset (formed once, before the loop) + pixel: the 64-bit
+        // (n * MR + row) * HW per request was ~16 quarter-rate multiplies per quad beside its 12 MFMAs
+        const T* sp = S + (long long)n * NS * HW + coloff;
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const uint4*>(sp + pxc[j]);
+        const T* rn = R + (long long)n * MR * HW;
 #pragma unroll
         for (int rb = 0; rb < WD_RB; ++rb) {
-            const long long roff = ((long long)n * MR + rowc[rb]) * HW;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                a[rb][j] = *reinterpret_cast<const uint4*>(R + roff + pxc[j]);
+                a[rb][j] = *reinterpret_cast<const uint4*>(rn + rowoff[rb] + pxc[j]);
             }
         }
         uint4 ya[XF == 3 ? WD_RB : 1][4];
         if constexpr (XF == 3) {
+            const T* yn = reinterpret_cast<const T*>(bx.y) + (long long)n * MR * HW;
 #pragma unroll
             for (int rb = 0; rb < WD_RB; ++rb) {
-                const long long roff = ((long long)n * MR + rowc[rb]) * HW;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    ya[rb][j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(bx.y) + roff + pxc[j]);
+                    ya[rb][j] = *reinterpret_cast<const uint4*>(yn + rowoff[rb] + pxc[j]);
             }
         }
 #pragma unroll
@@ -1612,12 +1627,16 @@ __global__ void __launch_bounds__(512) pw_wgrad_direct_kernel(const T* __restric
     }
     float* dst = part + (long long)split * MR * NS;
     if (cs) {
+        // rows row0 + 4h + {0..3, 8..11, 16..19, ...}: a running pointer (+NS, +NS, +NS, +5 NS) instead of a 64-bit r * NS
+        // per store (96 quarter-rate multiplies per wave for a loop of 4 quads)
+        float* p = dst + (long long)(row0 + 4 * h) * NS + col;
 #pragma unroll
         for (int rb = 0; rb < WD_RB; ++rb)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int r = row0 + 32 * rb + acc_row(reg, h);
-                if (r < MR) dst[(long long)r * NS + col] = acc[rb][reg];
+                if (r < MR) *p = acc[rb][reg];
+                p += (reg & 3) == 3 ? 5 * (long long)NS : (long long)NS;
             }
     }
 }
@@ -1719,12 +1738,16 @@ __global__ void __launch_bounds__(512) pw_wgrad_direct_f32_kernel(const float* _
     }
     float* dst = part + (long long)split * MR * NS;
     if (cs) {
+        // rows row0 + 4h + {0..3, 8..11, 16..19, ...}: a running pointer (+NS, +NS, +NS, +5 NS) instead of a 64-bit r * NS
+        // per store (96 quarter-rate multiplies per wave for a loop of 4 quads)
+        float* p = dst + (long long)(row0 + 4 * h) * NS + col;
 #pragma unroll
         for (int rb = 0; rb < WD_RB; ++rb)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int r = row0 + 32 * rb + acc_row(reg, h);
-                if (r < MR) dst[(long long)r * NS + col] = acc[rb][reg];
+                if (r < MR) *p = acc[rb][reg];
+                p += (reg & 3) == 3 ? 5 * (long long)NS : (long long)NS;
             }
     }
 }
