@@ -13,8 +13,9 @@
     images of equal size batched together (eval_ofa_net_sr.py); a "step" is one pass over the 14 images.
 
 Prints ONE JSON line on rank 0.  Besides the contract fields it carries
-  roofline      the kernel of the HIP library with the largest total time over the profiled steps (ALL library kernels
-                compete, on whichever stream they ran), timed live with HIP events attached to each kernel's own dispatch
+  roofline      the kernel of the HIP library with the largest total time (ALL library kernels compete, on whichever stream
+                they ran; ranked by the committed SERIALIZED trace of this command -- the concurrent ranking flips between
+                runs -- with the next two as `runners_up`), timed live with HIP events attached to each kernel's own dispatch
                 (hipExtLaunchKernel start / stop events, ofasr_profile_enable in include/ofasr.h: the kernel's begin -> end
                 time as rocprofv3's kernel trace reports it, no barrier packets added, streams overlap as in the timed
                 region) on the SAME composite path the timed region runs; `trace_avg_us` beside it is the average of the
@@ -277,54 +278,64 @@ def roofline_from(summ, nprof, dtype):
     cands = {k: v for k, v in summ.items() if v["launches"] > 0 and v["bytes"] > 0}
     if not cands:
         return None, table, None
-    # the dominant kernel: the one the committed rocprofv3 trace of this command puts on top (so that the line and
-    # profiles/ talk about the same kernel); without a trace for this dtype, the top of the live event table
-    name, chosen_by = None, "live event table (largest total time over the profiled steps)"
-    tr = trace_table(dtype)
-    if tr:
-        for k, _ in sorted(tr.items(), key=lambda kv: -kv[1].get("ms_per_step", 0.0)):
-            if k in cands:
-                name, chosen_by = k, "top library kernel of profiles/trace_summary.json (rocprofv3 --kernel-trace, static)"
-                break
-    if name is None:
-        name = max(cands.items(), key=lambda kv: kv[1]["total_us"])[0]
-    top = cands[name]
-    secs = top["total_us"] * 1e-6
+    # the dominant kernel: the library kernel with the largest total time in the committed rocprofv3 trace of this command
+    # with the dispatches SERIALIZED (the counter pass: every kernel's own cost; profiles/trace_summary.json key
+    # <dtype>_serialized), so that the line and profiles/ talk about the same kernel.  (The ranking of the CONCURRENT
+    # trace is not stable: a kernel's duration there depends on what the other stream happens to run beside it, and three
+    # consecutive profile runs of the same code put three different kernels on top.)  Without a serialized trace: the
+    # concurrent one; without any: the top of the live event table.
+    ranking, chosen_by = None, "live event table (largest total time over the profiled steps)"
+    for key, what in ((dtype + "_serialized", "serialized (rocprofv3 --kernel-trace --pmc: each kernel alone)"),
+                      (dtype, "concurrent (rocprofv3 --kernel-trace)")):
+        tr = trace_table(key)
+        names = [k for k, _ in sorted(tr.items(), key=lambda kv: -kv[1].get("ms_per_step", 0.0)) if k in cands]
+        if names:
+            ranking, chosen_by = names, "largest total time in profiles/trace_summary.json [%s], %s, static" % (key, what)
+            break
+    if ranking is None:
+        ranking = [k for k, _ in sorted(cands.items(), key=lambda kv: -kv[1]["total_us"])]
     peak_tf = MFMA_PEAK_TF[dtype]
-    # which roof bounds the kernel: its algorithmic intensity against the ridge (peak flops / peak bytes); the one-kernel
-    # MB block (9.3 GFLOP over 25 MB at N=16: 370 flop/B, ridge 312) and the static convs sit on the matrix side
-    mfma_bound = top["flops"] > 0 and top["flops"] / top["bytes"] > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
-    traffic, source = pmc_traffic(name)
-    trace_us, trace_src = trace_avg(name, dtype)
-    ser_us, ser_src = trace_avg(name, dtype + "_serialized")
-    if mfma_bound:
-        ach = top["flops"] / secs / 1e12
-        roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 1), "peak": peak_tf, "unit": "TFLOP/s",
-                "frac": round(ach / peak_tf, 4)}
-    else:
-        ach = top["bytes"] / secs / 1e9
-        roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4)}
-    roof.update({"traffic": traffic, "traffic_source": source,
-                 "avg_launch_us": round(top["total_us"] / top["launches"], 2),
-                 "launches_per_step": round(top["launches"] / nprof, 2),
-                 "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
-                 "hbm_gbps": round(top["bytes"] / secs / 1e9, 1),
-                 "mfma_tflops": round(top["flops"] / secs / 1e12, 2) if top["flops"] > 0 else None,
-                 "chosen_by": chosen_by,
-                 "trace_avg_us": trace_us, "trace_source": trace_src,
-                 "frac_trace": (round((top["flops"] if mfma_bound else top["bytes"]) / top["launches"] / (trace_us * 1e-6)
-                                      / ((peak_tf * 1e12) if mfma_bound else (HBM_PEAK_GBS * 1e9)), 4)
-                                if trace_us else None),
-                 # the same symbol with the dispatches serialized (the counter pass of the same command): the kernel alone
-                 # on the GPU.  trace_avg_us is what the step pays with the other stream's kernels on the same CUs.
-                 "serialized_avg_us": ser_us, "serialized_source": ser_src,
-                 "frac_serialized": (round((top["flops"] if mfma_bound else top["bytes"]) / top["launches"] / (ser_us * 1e-6)
-                                           / ((peak_tf * 1e12) if mfma_bound else (HBM_PEAK_GBS * 1e9)), 4)
-                                     if ser_us else None),
-                 "timing": "start/stop events attached to each kernel dispatch (hipExtLaunchKernel), composite path, "
-                           "%d profiled steps, both streams live" % nprof,
-                 "hip_library_ms_per_step": round(sum(v["total_us"] for v in summ.values()) * 1e-3 / nprof, 3)})
+
+    def roof_of(name, full):
+        top = cands[name]
+        secs = top["total_us"] * 1e-6
+        # which roof bounds the kernel: its algorithmic intensity against the ridge (peak flops / peak bytes); the
+        # one-kernel MB block (9.3 GFLOP over 25 MB at N=16: 370 flop/B, ridge 312) and the static convs sit on the
+        # matrix side
+        mfma_bound = top["flops"] > 0 and top["flops"] / top["bytes"] > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
+        work = (top["flops"] if mfma_bound else top["bytes"]) / top["launches"]
+        peak = (peak_tf * 1e12) if mfma_bound else (HBM_PEAK_GBS * 1e9)
+        trace_us, trace_src = trace_avg(name, dtype)
+        ser_us, ser_src = trace_avg(name, dtype + "_serialized")
+        if mfma_bound:
+            ach = top["flops"] / secs / 1e12
+            roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 1), "peak": peak_tf, "unit": "TFLOP/s",
+                    "frac": round(ach / peak_tf, 4)}
+        else:
+            ach = top["bytes"] / secs / 1e9
+            roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4)}
+        roof.update({"avg_launch_us": round(top["total_us"] / top["launches"], 2),
+                     "launches_per_step": round(top["launches"] / nprof, 2),
+                     # the same symbol in the committed traces: concurrent = what the step pays with the other stream's
+                     # kernels on the same CUs; serialized = the kernel alone on the GPU
+                     "trace_avg_us": trace_us, "frac_trace": round(work / (trace_us * 1e-6) / peak, 4) if trace_us else None,
+                     "serialized_avg_us": ser_us,
+                     "frac_serialized": round(work / (ser_us * 1e-6) / peak, 4) if ser_us else None})
+        if full:
+            traffic, source = pmc_traffic(name)
+            roof.update({"traffic": traffic, "traffic_source": source,
+                         "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
+                         "hbm_gbps": round(top["bytes"] / secs / 1e9, 1),
+                         "mfma_tflops": round(top["flops"] / secs / 1e12, 2) if top["flops"] > 0 else None,
+                         "chosen_by": chosen_by, "trace_source": trace_src, "serialized_source": ser_src,
+                         "timing": "start/stop events attached to each kernel dispatch (hipExtLaunchKernel), composite "
+                                   "path, %d profiled steps, both streams live" % nprof,
+                         "hip_library_ms_per_step": round(sum(v["total_us"] for v in summ.values()) * 1e-3 / nprof, 3)})
+        return roof
+
+    roof = roof_of(ranking[0], True)
+    roof["runners_up"] = [roof_of(k, False) for k in ranking[1:3]]   # the next two by the same ranking, same three figures
     # the 1x1 path (north_star: >= 70 % of the fp16/bf16 MFMA roofline is quoted against this)
     pw = [v for k, v in summ.items() if k.startswith("pw_") and v["flops"] > 0]
     pointwise = None
