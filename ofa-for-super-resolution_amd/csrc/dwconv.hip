@@ -1285,6 +1285,28 @@ int dwconv_stat_units(int64_t N, int64_t H, int64_t W, int K, int dtype) {
     return (int)(N * vg.nslabs);
 }
 
+// plain depthwise forward whose kernel also leaves the statistics partials of y ([C][N * slabs] (sum, sum of squares),
+// dwconv_stat_units) -- any element type, where the vector kernel applies (the un-fused composite path: fp32)
+bool dwconv_stat_supported(const void* x, const void* y, int64_t H, int64_t W, int K, int dtype) {
+    VecGeom vg;
+    const int pxl = (K <= 3 && dtype != OFASR_F32) ? 8 : 4;
+    if (dtype != OFASR_F32 && mfma_geom_ok(H, W, K, x, y)) return vec_geom(H, W, 2, 4, x, y, vg);
+    return vec_geom(H, W, dtype == OFASR_F32 ? 4 : 2, pxl, x, y, vg);
+}
+int dwconv_fwd_stat(const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H, int64_t W, int K, int dtype,
+                    StatOut so, void* stream) {
+    const char* name = "dwconv_fwd_stat";
+    int rc = check_conv_args(name, x, f, y, N, C, H, W, K, dtype);
+    if (rc) return rc;
+    OFASR_REQUIRE(so.partial != nullptr && dwconv_stat_supported(x, y, H, W, K, dtype), OFASR_ERR_UNSUPPORTED,
+                  "%s: needs the vector kernel and a statistics buffer", name);
+    if (N * C * H * W == 0) return OFASR_OK;
+    hipStream_t st = as_stream(stream);
+    if (dtype == OFASR_F32) return launch_conv<float, false, false, true>(name, x, f, y, N, C, H, W, K, st, InputXf{}, so);
+    if (dtype == OFASR_F16) return launch_conv<f16_t, false, false, true>(name, x, f, y, N, C, H, W, K, st, InputXf{}, so);
+    return launch_conv<bf16_t, false, false, true>(name, x, f, y, N, C, H, W, K, st, InputXf{}, so);
+}
+
 int dwconv_fwd_xf(const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H, int64_t W, int K, int dtype,
                   InputXf xf, void* stream, StatOut so, BnFold fold) {
     const char* name = "dwconv_fwd_xf";

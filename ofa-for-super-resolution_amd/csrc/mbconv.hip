@@ -270,7 +270,7 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
     // a switch (OFASR_PW_EPILOGUE_STATS=0 goes back to the pass); the depthwise kernel's statistics are free (one wave
     // owns a whole plane).
     static const bool pw_stat = [] { const char* e = getenv("OFASR_PW_EPILOGUE_STATS"); return !(e && e[0] == '0'); }();
-    if (fused && pw_stat && d->bn_training[0])
+    if (pw_stat && d->bn_training[0])   // fused or not: the un-fused path folds the partials in its BN apply (below)
         rc = pwconv_fwd_stat(x, d->w1, d->ldw1, y1, d->N, d->Cin, d->mid, HW, d->dtype,
                              StatOut{(float2*)workspace, pwconv_stat_units(d->N, d->Cin, HW)}, stream);
     else
@@ -360,17 +360,51 @@ OFASR_EXPORT int ofasr_mbconv_fwd(const ofasr_mbconv_desc* d, const void* x, voi
         return ofasr_bn_act_fwd(y3, d->residual ? x : nullptr, out, s3.scale, s3.shift, s3.mean, d->N, d->Cout, HW, 0,
                                 d->dtype, stream);
     }
-    rc = bn_forward(d, 0, y1, nullptr, a1, d->mid, 1, stat_buf, workspace, workspace_bytes, stream);
+    // Un-fused path (fp32 activations, or shapes the fused reads do not cover).  The 1x1 convs still leave their output's
+    // statistics partials in the epilogue (the generic kernels take a StatOut for every element type) and the BN apply
+    // folds them in its blocks (bn_fwd_cp): no statistics pass over y1 / y3 (round 3: 28 + 14 bn_stats launches off the
+    // fp32 step).
+    const bool cp1 = pw_stat && d->bn_training[0], cp3 = pw_stat && d->bn_training[2];
+    if (cp1) {
+        const int P1 = pwconv_stat_units(d->N, d->Cin, HW);
+        StatView sv = stat_view(stat_buf, 0, d->mid, d->Cout);
+        rc = bn_fwd_cp(y1, nullptr, a1, (const float2*)workspace, P1, d->gamma[0], d->beta[0], d->running_mean[0],
+                       d->running_var[0], d->bn_momentum[0], d->bn_eps[0], d->bn_training[0], sv.mean, d->N, d->mid, HW, 1,
+                       d->dtype, stream);
+    } else {
+        rc = bn_forward(d, 0, y1, nullptr, a1, d->mid, 1, stat_buf, workspace, workspace_bytes, stream);
+    }
     if (rc) return rc;
     // active depthwise filter -> depthwise -> BN + ReLU6
     rc = (t_skip_kt & 1) ? OFASR_OK : ofasr_ktransform_fwd(d->wdw_max, d->ks, d->chain_len - 1, d->mats, d->transform, f, d->mid,
                               stream);
     if (rc) return rc;
-    rc = ofasr_dwconv_fwd(a1, f, y2, d->N, d->mid, d->H, d->W, d->K, d->dtype, stream);
-    if (rc) return rc;
-    rc = bn_forward(d, 1, y2, nullptr, a2, d->mid, 1, stat_buf, workspace, workspace_bytes, stream);
+    const int P2u = dwconv_stat_units(d->N, d->H, d->W, d->K, d->dtype);
+    if (pw_stat && d->bn_training[1] && P2u > 0 && dwconv_stat_supported(a1, y2, d->H, d->W, d->K, d->dtype)) {
+        // the depthwise kernel's statistics are free (a wave owns whole rows of one plane): BN2 without its statistics pass
+        rc = dwconv_fwd_stat(a1, f, y2, d->N, d->mid, d->H, d->W, d->K, d->dtype, StatOut{(float2*)workspace, P2u}, stream);
+        if (rc) return rc;
+        StatView sv = stat_view(stat_buf, 1, d->mid, d->Cout);
+        rc = bn_fwd_cp(y2, nullptr, a2, (const float2*)workspace, P2u, d->gamma[1], d->beta[1], d->running_mean[1],
+                       d->running_var[1], d->bn_momentum[1], d->bn_eps[1], d->bn_training[1], sv.mean, d->N, d->mid, HW, 1,
+                       d->dtype, stream);
+    } else {
+        rc = ofasr_dwconv_fwd(a1, f, y2, d->N, d->mid, d->H, d->W, d->K, d->dtype, stream);
+        if (rc) return rc;
+        rc = bn_forward(d, 1, y2, nullptr, a2, d->mid, 1, stat_buf, workspace, workspace_bytes, stream);
+    }
     if (rc) return rc;
     // project 1x1 -> BN (+ shortcut)
+    if (cp3) {
+        const int P3 = pwconv_stat_units(d->N, d->mid, HW);
+        rc = pwconv_fwd_stat(a2, d->w2, d->ldw2, y3, d->N, d->mid, d->Cout, HW, d->dtype, StatOut{(float2*)workspace, P3},
+                             stream);
+        if (rc) return rc;
+        StatView s3 = stat_view(stat_buf, 2, d->mid, d->Cout);
+        return bn_fwd_cp(y3, d->residual ? x : nullptr, out, (const float2*)workspace, P3, d->gamma[2], d->beta[2],
+                         d->running_mean[2], d->running_var[2], d->bn_momentum[2], d->bn_eps[2], d->bn_training[2], s3.mean,
+                         d->N, d->Cout, HW, 0, d->dtype, stream);
+    }
     rc = ofasr_pwconv_fwd(a2, d->w2, d->ldw2, y3, d->N, d->mid, d->Cout, HW, d->dtype, stream);
     if (rc) return rc;
     return bn_forward(d, 2, y3, d->residual ? x : nullptr, out, d->Cout, 0, stat_buf, workspace, workspace_bytes,

@@ -390,6 +390,9 @@ int conv_thin_in(const void* x, const float* w, void* y, int64_t N, int64_t Ct, 
 // internal (not exported) variants used by mbconv.hip; they return OFASR_ERR_UNSUPPORTED (and launch nothing) when
 // the vector / aligned 16-bit kernels that implement the fused read do not apply to the shape.
 bool dwconv_xf_supported(const void* x, const void* y, int64_t H, int64_t W, int K, int dtype);
+bool dwconv_stat_supported(const void* x, const void* y, int64_t H, int64_t W, int K, int dtype);
+int dwconv_fwd_stat(const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H, int64_t W, int K, int dtype,
+                    StatOut so, void* stream);
 int dwconv_fwd_xf(const void* x, const float* f, void* y, int64_t N, int64_t C, int64_t H, int64_t W, int K, int dtype,
                   InputXf xf, void* stream, StatOut so = StatOut{nullptr, 0}, BnFold fold = BnFold{});
 int dwconv_wgrad_xf(const void* dy, const void* x, float* df, int64_t N, int64_t C, int64_t H, int64_t W, int K,
