@@ -192,7 +192,7 @@ def test_fused_and_modular_paths_agree():
 
 def test_composite_block_matches_per_op_path():
     """ofasr_mbconv_fwd/_bwd (one FFI call per block and direction) vs the per-op autograd Functions.  fp32: same kernels
-    in the same order, outputs and every gradient agree to round-off.  16-bit: the composite call applies BN1/BN2 + ReLU6
+    in the same order (statistics from the conv epilogues in the composite call), outputs and every gradient agree to 1e-4.  16-bit: the composite call applies BN1/BN2 + ReLU6
     inside the consumer kernels from the pre-BN tensor (the activated tensor is never rounded to 16 bits), so it is a
     different -- not a worse -- 16-bit realisation: both are measured against the fp32 result in the L2 norm
     (tools/chk_fused.py prints the numbers: 4.7 % vs 4.6 % on dx in train mode, 0.4 % on y)."""
@@ -234,15 +234,20 @@ def test_composite_block_matches_per_op_path():
         sd = {kk: v.clone() for kk, v in block.state_dict().items()}
         (ya, xa, ga, ba) = run(block, sd, x0, dy, torch.float32, True)
         (yb, xb, gb, bb) = run(block, sd, x0, dy, torch.float32, False)
-        tol = 1e-5
+        # same kernels in the same order, except the batch statistics: the composite call takes them from the conv
+        # kernels' epilogues (fp32 (sum, sum of squares) per tile, fp64 fold), the per-op path from the fp64 statistics
+        # pass -- 2e-5 on a BN weight gradient (a difference of large sums)
+        tol = 1e-4
         assert float((ya - yb).abs().max()) <= tol * max(1.0, float(yb.abs().max()))
         assert float((xa - xb).abs().max()) <= tol * max(1.0, float(xb.abs().max()))
         for n in ga:
             assert (ga[n] is None) == (gb[n] is None), n
             if ga[n] is not None:
-                assert float((ga[n] - gb[n]).abs().max()) <= tol * max(1e-3, float(gb[n].abs().max())), n
+                # (BN parameter gradients are sums of O(N*H*W) = 768 signed O(1) terms that nearly cancel: their round-off
+                # is absolute, ~768 * 2^-24 per re-ordering, whatever the size of the sum)
+                assert float((ga[n] - gb[n]).abs().max()) <= tol * max(1.0 if ".bn." in n else 1e-3, float(gb[n].abs().max())), n
         for n in ba:
-            assert torch.allclose(ba[n].float(), bb[n].float(), rtol=1e-5, atol=1e-6), n
+            assert torch.allclose(ba[n].float(), bb[n].float(), rtol=5e-5, atol=2e-6), n
         # 16-bit: composite (fused BN apply) and per-op, each against the fp32 per-op result
         (yc, xc, gc, bc) = run(block, sd, x0, dy, torch.bfloat16, True)
         (yd, xd, gd, bd) = run(block, sd, x0, dy, torch.bfloat16, False)
